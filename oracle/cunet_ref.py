@@ -1,0 +1,271 @@
+"""CPU oracle: stock-PyTorch fp32 restatement of the reference hot path.
+
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  Nothing under
+``weather-unet_amd/`` imports this file; it is the checker, never the product.
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` (run in the build
+container, where ``/root/reference`` is importable) checks every function here
+against the reference's own modules on the same weights/inputs (max-abs 0.0)
+and writes the golden vectors in ``tests/golden/*.npz`` that
+``tests/test_oracle_golden.py`` re-checks on every run.  The arithmetic lives
+in PyTorch (reference pins torch==1.1.0, Pipfile:10; oracle of record is
+torch 2.10 CPU fp32).
+
+Each function cites the reference lines it follows.  All tensors are NCHW fp32
+(the reference layout); parameters use the reference's state-dict key names.
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# deterministic parameter fill (build-owned; reproducible without the reference)
+# --------------------------------------------------------------------------------------
+
+G_CHANNELS = [(3, 64), (64, 128), (128, 256), (256, 512)]          # cunet.py:21-24
+G_UP = [(256 + 512, 256), (128 + 256, 128), (64 + 128, 64)]        # cunet.py:34-36
+ADAIN_CH = {"adain3": 512, "adain2": 256, "adain1": 128}           # cunet.py:30-32
+
+
+def _rng(name, seed):
+    return np.random.default_rng([zlib.crc32(name.encode()), seed])
+
+
+def _uniform(name, shape, bound, seed):
+    a = _rng(name, seed).uniform(-bound, bound, size=shape).astype(np.float32)
+    return torch.from_numpy(a)
+
+
+def cunet_param_shapes(num_classes):
+    """The 39 state-dict keys of Conditional_UNet (cunet.py:18-41) and their shapes."""
+    shapes = {}
+    blocks = {f"dconv_down{i + 1}": ch for i, ch in enumerate(G_CHANNELS)}
+    blocks.update({f"dconv_up{3 - i}": ch for i, ch in enumerate(G_UP)})
+    for name, (cin, cout) in blocks.items():
+        shapes[f"{name}.0.weight"] = (cout, cin, 3, 3)       # nets.py:20
+        shapes[f"{name}.0.bias"] = (cout,)
+        shapes[f"{name}.2.weight"] = (cout, cout, 3, 3)      # nets.py:22
+        shapes[f"{name}.2.bias"] = (cout,)
+    for name, ch in ADAIN_CH.items():
+        shapes[f"{name}.l1.weight"] = (4 * ch, num_classes)  # utils.py:31
+        shapes[f"{name}.l1.bias"] = (4 * ch,)
+        shapes[f"{name}.emb.weight"] = (num_classes, num_classes)  # utils.py:32 (unused)
+    shapes["conv_last.weight"] = (3, 64, 1, 1)               # cunet.py:39
+    shapes["conv_last.bias"] = (3,)
+    return shapes
+
+
+def make_cunet_params(num_classes=5, seed=0, gain=1.0):
+    """Deterministic fill: U(-b, b), b = gain*sqrt(3/fan_in) for weights (variance-preserving
+    with ReLU roughly halved, so activations stay O(1) through 15 convs), small biases."""
+    params = {}
+    for k, shp in sorted(cunet_param_shapes(num_classes).items()):
+        if k.endswith("emb.weight"):
+            params[k] = _uniform(k, shp, 1.0, seed)
+        elif k.endswith("weight"):
+            fan_in = int(np.prod(shp[1:]))
+            g = gain * (math.sqrt(2.0) if ".l1." not in k and k != "conv_last.weight" else 1.0)
+            params[k] = _uniform(k, shp, g * math.sqrt(3.0 / fan_in), seed)
+        else:
+            params[k] = _uniform(k, shp, 0.1, seed)
+    return params
+
+
+D_CHANNELS = [(3, 64), (64, 128), (128, 256), (256, 512)]          # disc.py:12-15
+
+
+def sndisc_param_shapes(num_classes):
+    """The 40 state-dict keys of SNDisc (disc.py:10-25): 10 spectral-norm layers x
+    {bias, weight_orig, weight_u, weight_v}."""
+    shapes = {}
+    for i, (cin, cout) in enumerate(D_CHANNELS, start=1):
+        for j, (ci, co) in enumerate([(cin, cin), (cin, cout)]):   # nets.py:28-31
+            p = f"conv{i}.{j}"
+            shapes[p + ".bias"] = (co,)
+            shapes[p + ".weight_orig"] = (co, ci, 3, 3)
+            shapes[p + ".weight_u"] = (co,)
+            shapes[p + ".weight_v"] = (ci * 9,)
+    for p, (co, ci) in {"l": (1, 512), "embed": (512, num_classes)}.items():  # disc.py:21,24
+        shapes[p + ".bias"] = (co,)
+        shapes[p + ".weight_orig"] = (co, ci)
+        shapes[p + ".weight_u"] = (co,)
+        shapes[p + ".weight_v"] = (ci,)
+    return shapes
+
+
+def make_sndisc_params(num_classes=5, seed=0):
+    params = {}
+    for k, shp in sorted(sndisc_param_shapes(num_classes).items()):
+        if k.endswith("weight_orig"):
+            fan_in = int(np.prod(shp[1:]))
+            params[k] = _uniform(k, shp, math.sqrt(6.0 / fan_in), seed)
+        elif k.endswith("weight_u") or k.endswith("weight_v"):
+            v = torch.from_numpy(_rng(k, seed).standard_normal(shp).astype(np.float32))
+            params[k] = F.normalize(v, dim=0, eps=1e-12)
+        else:
+            params[k] = _uniform(k, shp, 0.1, seed)
+    return params
+
+
+def make_inputs(batch, size, num_classes=5, seed=0, soft=False):
+    """x ~ U(-1,1) (the Normalize(0.5,0.5) range, t_cls_train.py:93); c = one-hot rows
+    (class = i % nc) or softmax(N(0,1)) rows."""
+    r = _rng("inputs", seed)
+    x = torch.from_numpy(r.uniform(-1, 1, size=(batch, 3, size, size)).astype(np.float32))
+    if soft:
+        c = torch.softmax(torch.from_numpy(r.standard_normal((batch, num_classes)).astype(np.float32)), 1)
+    else:
+        c = torch.eye(num_classes)[torch.arange(batch) % num_classes]
+    return x, c
+
+
+# --------------------------------------------------------------------------------------
+# generator: Conditional_UNet.forward   (cunet.py:43-82)
+# --------------------------------------------------------------------------------------
+
+def r_double_conv(p, name, x):
+    """nets.py:18-24: Conv3x3(pad 1, bias) -> ReLU -> Conv3x3 -> ReLU."""
+    x = F.relu(F.conv2d(x, p[f"{name}.0.weight"], p[f"{name}.0.bias"], padding=1))
+    x = F.relu(F.conv2d(x, p[f"{name}.2.weight"], p[f"{name}.2.bias"], padding=1))
+    return x
+
+
+def c_norm(x, bs, ch, eps):
+    """utils.py:34-39: unbiased var over the last dim, +eps, sqrt; mean."""
+    x_var = x.var(dim=-1) + eps
+    x_std = x_var.sqrt().view(bs, ch, 1, 1)
+    x_mean = x.mean(dim=-1).view(bs, ch, 1, 1)
+    return x_std, x_mean
+
+
+def adain(p, name, x, y, eps=1e-5):
+    """utils.py:41-51.  y_ = l1(y).view(bs, ch, 4); both x and y_ normalised with eps=self.eps."""
+    size = x.size()
+    bs, ch = size[:2]
+    x_ = x.view(bs, ch, -1)
+    y_ = F.linear(y, p[f"{name}.l1.weight"], p[f"{name}.l1.bias"]).view(bs, ch, -1)
+    x_std, x_mean = c_norm(x_, bs, ch, eps)
+    y_std, y_mean = c_norm(y_, bs, ch, eps)
+    return ((x - x_mean.expand(size)) / x_std.expand(size)) * y_std.expand(size) + y_mean.expand(size)
+
+
+def upsample2(x):
+    """cunet.py:26: nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)."""
+    return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+
+
+def dropout(x, mask, p=0.3):
+    """cunet.py:28 nn.Dropout(p=0.3): keep-mask (1 = keep) scaled by 1/(1-p); mask None = eval."""
+    if mask is None:
+        return x
+    return x * mask.to(x.dtype) * (1.0 / (1.0 - p))
+
+
+def cunet_forward(p, x, c, masks=None, return_stages=False):
+    """Conditional_UNet.forward (cunet.py:43-82).  ``masks`` = None (eval mode) or a list of
+    three keep-masks for the dropouts at cunet.py:61,68,75 (train mode with a known mask)."""
+    m3, m2, m1 = masks if masks is not None else (None, None, None)
+    st = {}
+    conv1 = r_double_conv(p, "dconv_down1", x)               # :45
+    x = F.max_pool2d(conv1, 2)                               # :46
+    conv2 = r_double_conv(p, "dconv_down2", x)               # :48
+    x = F.max_pool2d(conv2, 2)                               # :49
+    conv3 = r_double_conv(p, "dconv_down3", x)               # :51
+    x = F.max_pool2d(conv3, 2)                               # :52
+    x = r_double_conv(p, "dconv_down4", x)                   # :54
+    st.update(conv1=conv1, conv2=conv2, conv3=conv3, bottleneck=x)
+    x = adain(p, "adain3", x, c)                             # :59
+    st["adain3"] = x
+    x = torch.cat([dropout(upsample2(x), m3), conv3], dim=1)  # :60-62
+    x = r_double_conv(p, "dconv_up3", x)                     # :64
+    st["up3"] = x
+    x = adain(p, "adain2", x, c)                             # :66
+    st["adain2"] = x
+    x = torch.cat([dropout(upsample2(x), m2), conv2], dim=1)  # :67-69
+    x = r_double_conv(p, "dconv_up2", x)                     # :71
+    st["up2"] = x
+    x = adain(p, "adain1", x, c)                             # :73
+    st["adain1"] = x
+    x = torch.cat([dropout(upsample2(x), m1), conv1], dim=1)  # :74-76
+    x = r_double_conv(p, "dconv_up1", x)                     # :78
+    st["up1"] = x
+    out = torch.tanh(F.conv2d(x, p["conv_last.weight"], p["conv_last.bias"]))  # :80-82
+    if return_stages:
+        return out, st
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# discriminator: SNDisc.forward   (disc.py:27-38) with torch.nn.utils.spectral_norm
+# --------------------------------------------------------------------------------------
+
+def spectral_normalize(w_orig, u, v, train=True, eps=1e-12):
+    """torch.nn.utils.spectral_norm (nets.py:28-31, disc.py:21,24), n_power_iterations=1.
+    Train mode: v <- normalize(W^T u); u <- normalize(W v) (under no_grad, buffers updated),
+    then sigma = u . (W v) and W / sigma.  Returns (w, u_new, v_new)."""
+    w_mat = w_orig.reshape(w_orig.shape[0], -1)
+    if train:
+        with torch.no_grad():
+            v = F.normalize(torch.mv(w_mat.t(), u), dim=0, eps=eps)
+            u = F.normalize(torch.mv(w_mat, v), dim=0, eps=eps)
+    sigma = torch.dot(u, torch.mv(w_mat, v))
+    return w_orig / sigma, u, v
+
+
+def sn_double_conv(p, name, x, train, new_buffers):
+    """nets.py:26-33: SN(Conv3x3 cin->cin s1 p1) -> SN(Conv3x3 cin->cout s2 p1) -> LeakyReLU(0.2);
+    no activation between the two convs."""
+    for j, stride in ((0, 1), (1, 2)):
+        k = f"{name}.{j}"
+        w, u, v = spectral_normalize(p[k + ".weight_orig"], p[k + ".weight_u"], p[k + ".weight_v"], train)
+        new_buffers[k + ".weight_u"], new_buffers[k + ".weight_v"] = u, v
+        x = F.conv2d(x, w, p[k + ".bias"], stride=stride, padding=1)
+    return F.leaky_relu(x, 0.2)
+
+
+def sndisc_forward(p, x, c, train=True):
+    """SNDisc.forward (disc.py:27-38).  Returns ([out, c1, c2, c3, c4], new_buffers) where
+    new_buffers holds the power-iteration-updated weight_u / weight_v of the 10 SN layers."""
+    nb = {}
+    c1 = sn_double_conv(p, "conv1", x, train, nb)            # :28
+    c2 = sn_double_conv(p, "conv2", c1, train, nb)           # :29
+    c3 = sn_double_conv(p, "conv3", c2, train, nb)           # :30
+    c4 = sn_double_conv(p, "conv4", c3, train, nb)           # :31
+    feat = torch.sum(c4, [2, 3])                             # :32 global sum pool
+    w, u, v = spectral_normalize(p["l.weight_orig"], p["l.weight_u"], p["l.weight_v"], train)
+    nb["l.weight_u"], nb["l.weight_v"] = u, v
+    out = F.linear(feat, w, p["l.bias"])                     # :33
+    w, u, v = spectral_normalize(p["embed.weight_orig"], p["embed.weight_u"], p["embed.weight_v"], train)
+    nb["embed.weight_u"], nb["embed.weight_v"] = u, v
+    e_c = F.linear(c, w, p["embed.bias"])                    # :34
+    out = out + torch.sum(e_c * feat, dim=1, keepdim=True)   # :36
+    return [out, c1, c2, c3, c4], nb
+
+
+# --------------------------------------------------------------------------------------
+# losses (ops.py) -- restated for the step harness checks
+# --------------------------------------------------------------------------------------
+
+def dis_hinge(dis_fake, dis_real):
+    """ops.py:42-45."""
+    return torch.mean(torch.relu(1.0 - dis_real)) + torch.mean(torch.relu(1.0 + dis_fake))
+
+
+def gen_hinge(dis_fake):
+    """ops.py:47-48."""
+    return torch.mean(-dis_fake)
+
+
+def recon_loss(fake, img, pred, r):
+    """t_cls_train.py:264-266: mean( mean|fake-img|_CHW / (mean|pred-r|_nc + 1e-7) )."""
+    diff = torch.mean(torch.abs(fake - img), [1, 2, 3])
+    lmda = torch.mean(torch.abs(pred - r), 1)
+    return torch.mean(diff / (lmda + 1e-7))
+
+
+def bench_loss(out, x):
+    """The pure fwd+bwd benchmark's scalar loss: mean|G(x,c) - x|."""
+    return torch.mean(torch.abs(out - x))

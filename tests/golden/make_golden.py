@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/ by running the REFERENCE itself on CPU.
+
+Run in the build container only (``/root/reference`` does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python3 -O tests/golden/make_golden.py
+
+``-O`` strips the reference's ``assert isinstance(x, torch.cuda.FloatTensor)`` (utils.py:35) so
+AdaIN runs on CPU; ``torchvision`` (imported by utils.py:5 only for the off-path ``Denormalize``)
+is stubbed in ``sys.modules``.  The reference files are imported, never copied.
+
+For every case the script (1) loads the build-owned deterministic parameters into the reference
+module, (2) runs the reference, (3) runs the oracle restatement (oracle/cunet_ref.py) on the
+same tensors and REQUIRES max-abs 0.0 between the two, (4) stores inputs-by-seed + reference
+outputs (full tensors where small, else mean / abs-max / strided samples) as .npz fixtures.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.path.insert(0, "/root/reference")
+import cunet as ref_cunet  # noqa: E402  (the reference)
+import disc as ref_disc    # noqa: E402
+
+from oracle import cunet_ref as O  # noqa: E402
+
+torch.set_num_threads(8)
+NC = 5
+
+
+def summary(t, nsamp=64):
+    t = t.detach().reshape(-1).double()
+    idx = torch.linspace(0, t.numel() - 1, nsamp).long()
+    return np.concatenate([[t.mean().item(), t.abs().max().item(), t.pow(2).mean().sqrt().item()],
+                           t[idx].numpy()]).astype(np.float64)
+
+
+def exact(a, b, what):
+    d = (a - b).abs().max().item()
+    assert d == 0.0, f"oracle restatement differs from the reference at {what}: max-abs {d}"
+
+
+def gen_case(tag, batch, size, soft, seed, full_output):
+    p = O.make_cunet_params(NC, seed)
+    net = ref_cunet.Conditional_UNet(NC)
+    missing = net.load_state_dict(p, strict=True)
+    net.eval()
+    x, c = O.make_inputs(batch, size, NC, seed, soft)
+    hooks, stages = [], {}
+    names = {"dconv_down1": "conv1", "dconv_down2": "conv2", "dconv_down3": "conv3",
+             "dconv_down4": "bottleneck", "adain3": "adain3", "adain2": "adain2", "adain1": "adain1",
+             "dconv_up3": "up3", "dconv_up2": "up2", "dconv_up1": "up1"}
+    for mod, key in names.items():
+        hooks.append(getattr(net, mod).register_forward_hook(
+            lambda m, i, o, key=key: stages.__setitem__(key, o.detach().clone())))
+    with torch.no_grad():
+        y_ref = net(x, c)
+    for h in hooks:
+        h.remove()
+    with torch.no_grad():
+        y_or, st = O.cunet_forward(p, x, c, None, return_stages=True)
+    exact(y_ref, y_or, f"{tag} output")
+    out = {"meta": np.array([batch, size, int(soft), seed, NC]), "out_summary": summary(y_ref)}
+    for k, v in stages.items():
+        exact(v, st[k], f"{tag} stage {k}")
+        out["stage_" + k] = summary(v)
+    if full_output:
+        out["out"] = y_ref.numpy()
+
+    # gradients of the benchmark loss mean|G(x,c) - x| (eval mode = dropout identity)
+    net.zero_grad()
+    loss = torch.mean(torch.abs(net(x, c) - x))
+    loss.backward()
+    pg = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss_o = O.bench_loss(O.cunet_forward(pg, x, c), x)
+    loss_o.backward()
+    exact(loss.detach(), loss_o.detach(), f"{tag} loss")
+    out["loss"] = np.array([loss.item()])
+    for k, prm in net.named_parameters():
+        if prm.grad is None:
+            assert k.endswith("emb.weight")
+            continue
+        exact(prm.grad, pg[k].grad, f"{tag} grad {k}")
+        out["grad_" + k] = summary(prm.grad)
+    np.savez_compressed(os.path.join(OUT, f"cunet_{tag}.npz"), **out)
+    print(f"cunet_{tag}: out abs-max {y_ref.abs().max():.4f} mean {y_ref.mean():.4f} loss {loss.item():.5f}")
+
+
+def gen_train_case(tag, batch, size, seed):
+    """Train mode (dropout active, as in the inference scripts that never call .eval(),
+    inf_transfer_c.py:88-96).  nn.Dropout on CPU draws empty_like(x).bernoulli_(1-p) per call, so
+    re-seeding and drawing the three masks in call order reproduces the reference's masks."""
+    p = O.make_cunet_params(NC, seed)
+    net = ref_cunet.Conditional_UNet(NC)
+    net.load_state_dict(p, strict=True)
+    net.train()
+    x, c = O.make_inputs(batch, size, NC, seed, True)
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        y_ref = net(x, c)
+    torch.manual_seed(1234)
+    s = size // 4
+    masks = []
+    for ch, hw in ((512, s), (256, 2 * s), (128, 4 * s)):
+        masks.append(torch.empty(batch, ch, hw, hw).bernoulli_(0.7))
+    with torch.no_grad():
+        y_or = O.cunet_forward(p, x, c, masks)
+    exact(y_ref, y_or, f"{tag} train-mode output with reproduced masks")
+    packed = [np.packbits(m.numpy().astype(np.uint8).reshape(-1)) for m in masks]
+    np.savez_compressed(os.path.join(OUT, f"cunet_{tag}.npz"), meta=np.array([batch, size, 1, seed, NC]),
+                        out=y_ref.numpy(), mask3=packed[0], mask2=packed[1], mask1=packed[2])
+    print(f"cunet_{tag}: train-mode out abs-max {y_ref.abs().max():.4f}")
+
+
+def gen_disc(tag, batch, size, seed):
+    p = O.make_sndisc_params(NC, seed)
+    net = ref_disc.SNDisc(NC)
+    net.load_state_dict(p, strict=True)
+    net.train()
+    x, c = O.make_inputs(batch, size, NC, seed, True)
+    outs = net(x, c)
+    loss = torch.mean(torch.relu(1.0 - outs[0]))
+    loss.backward()
+    pg = {k: (v.clone().requires_grad_(True) if k.endswith(("weight_orig", "bias")) else v.clone())
+          for k, v in p.items()}
+    outs_o, nb = O.sndisc_forward(pg, x, c, train=True)
+    loss_o = torch.mean(torch.relu(1.0 - outs_o[0]))
+    loss_o.backward()
+    out = {"meta": np.array([batch, size, 1, seed, NC]), "out": outs[0].detach().numpy(),
+           "loss": np.array([loss.item()])}
+    for i, (a, b) in enumerate(zip(outs, outs_o)):
+        exact(a, b, f"{tag} D output {i}")
+        out[f"o{i}_summary"] = summary(a)
+    sd = net.state_dict()
+    for k, v in nb.items():
+        exact(sd[k], v, f"{tag} buffer {k}")
+        out["buf_" + k] = v.numpy()
+    for k, prm in net.named_parameters():
+        exact(prm.grad, pg[k].grad, f"{tag} grad {k}")
+        out["grad_" + k] = summary(prm.grad)
+    # a second forward in eval mode (no power iteration) on the updated buffers
+    net.eval()
+    with torch.no_grad():
+        outs_e = net(x, c)
+    p2 = dict(p)
+    p2.update(nb)
+    with torch.no_grad():
+        outs_eo, _ = O.sndisc_forward(p2, x, c, train=False)
+    exact(outs_e[0], outs_eo[0], f"{tag} eval-mode D output")
+    out["out_eval"] = outs_e[0].numpy()
+    np.savez_compressed(os.path.join(OUT, f"sndisc_{tag}.npz"), **out)
+    print(f"sndisc_{tag}: out {outs[0].detach().reshape(-1)[:4].numpy()} loss {loss.item():.5f}")
+
+
+if __name__ == "__main__":
+    assert not __debug__, "run with python3 -O (reference asserts CUDA tensors, utils.py:35)"
+    gen_case("c1_b2_128_onehot", 2, 128, False, 0, True)      # BASELINE.json configs[0]
+    gen_case("b2_64_soft", 2, 64, True, 1, True)
+    gen_case("b1_32_soft", 1, 32, True, 2, True)
+    gen_case("b3_96x_onehot", 3, 96, False, 3, False)
+    gen_train_case("train_b2_64", 2, 64, 4)
+    gen_disc("b2_64", 2, 64, 0)
+    gen_disc("b3_128", 3, 128, 1)
+    print("golden vectors written to", OUT)
