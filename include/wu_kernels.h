@@ -1,0 +1,165 @@
+/*
+ * wu_kernels.h -- C ABI of libwu_kernels.so, the MI355X (gfx950) kernels behind the
+ * conditional-U-Net hot path of Sota0726/weather-Unet.
+ *
+ * The reference has no native code: every entry point below replaces a torch.nn op that the
+ * reference's Python modules call (file:line cited per function).  The reference-side binding
+ * is the ctypes stub shown in INTEGRATION.md (weather-unet_amd/wu/_lib.py is that stub).
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers unless said otherwise.  The library never allocates,
+ *     frees or synchronises: buffers and workspaces are owned by the caller and only borrowed
+ *     for the duration of the launch; every call only enqueues work on `stream`
+ *     (a hipStream_t passed as void*), so calls are graph-capturable and re-entrant.
+ *   - Activations are NHWC ("channels-last"): element (n,h,w,c) of a tensor with pixel stride
+ *     `ld` (in elements, >= C, multiple of 8) lives at ((n*H + h)*W + w)*ld + c.  A channel
+ *     slice of a wider buffer is passed as (ptr + c0, ld = total channels); that is how the
+ *     skip-concat (cunet.py:62,69,76) is done without a copy.
+ *   - `dtype`: WU_F32 (0) = fp32 storage, exact-fp32 MFMA;  WU_BF16 (1) = bf16 storage,
+ *     bf16 MFMA with fp32 accumulation.  Parameters, their gradients, statistics are fp32.
+ *   - Network input / output images are NCHW fp32 (the reference's layout).
+ *   - Return value: 0 on success, a hipError_t (>0) from the launch, or < 0 for a rejected
+ *     argument (shape / alignment); wu_last_error() gives a host string for the last failure
+ *     on the calling thread.
+ */
+#ifndef WU_KERNELS_H
+#define WU_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WU_F32 0
+#define WU_BF16 1
+
+#define WU_ACT_NONE 0
+#define WU_ACT_RELU 1   /* nets.py:21,23 nn.ReLU */
+#define WU_ACT_LEAKY 2  /* nets.py:32 nn.LeakyReLU(0.2) */
+
+const char* wu_last_error(void);
+int wu_version(void);
+
+/* ---- weights -------------------------------------------------------------------------------
+ * Repack one 3x3 conv weight (nets.py:20,22,28-31; OIHW fp32, the state-dict layout) into the two
+ * MFMA operand layouts: w_fwd[tap][Cout][Cin] and w_dgrad[tap'][Cin][Cout] with tap' the
+ * 180-degree-rotated tap (the data-gradient is a correlation with the flipped, transposed
+ * filter).  `inv_sigma` (device scalar, may be NULL) multiplies every weight: the spectral-norm
+ * division W/sigma of torch.nn.utils.spectral_norm (nets.py:27-31).  Either output may be NULL. */
+int wu_pack_conv3x3(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin,
+                    const float* inv_sigma, int dtype, void* stream);
+
+/* ---- conv3x3, pad 1, MFMA implicit GEMM -----------------------------------------------------
+ * y = act(conv3x3(x, w) + bias)   replaces nn.Conv2d(cin,cout,3,padding=1[,stride=2]) + ReLU /
+ * LeakyReLU of nets.py:18-33.  x: (N,H,W,Cin) ld=ldx; y: (N,Ho,Wo,Cout) ld=ldy with
+ * Ho = (H-1)/stride + 1.  Cin % (64/sizeof(T)) == 0, Cout % 64 == 0.  bias may be NULL.
+ * If `mask` != NULL the staged input is gated by the activation derivative of `mask`
+ * (same geometry as x, ld=ldmask):  x * (mask > 0 ? 1 : slope(mask_act)) -- this is how the
+ * data-gradient pass (called with w_dgrad, Cin<->Cout swapped, stride 1) fuses the ReLU backward
+ * of autograd (t_cls_train.py:272,307) into its input gather. */
+int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                   int N, int H, int W, int Cin, int Cout, int stride, int act,
+                   const void* mask, int ldmask, int mask_act, int dtype, void* stream);
+
+/* Weight + bias gradient of the conv above: dw_oihw[Cout][Cin][3][3] (+)= sum_pixels dy (x) x,
+ * dbias[Cout] (+)= sum dy, with dy gated by act'(y) when `y` != NULL.  `workspace` must hold
+ * wu_conv3x3_wgrad_workspace() bytes (deterministic split-K slabs).  accumulate != 0 adds into
+ * dw/dbias (autograd's .grad accumulation), else overwrites. */
+size_t wu_conv3x3_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int stride, int dtype);
+int wu_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy_, int act,
+                     float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes,
+                     int N, int H, int W, int Cin, int Cout, int stride, int accumulate,
+                     int dtype, void* stream);
+
+/* Data gradient of the stride-2 conv (nets.py:30-31): dx (N,H,W,Cin) from dy (N,Ho,Wo,Cout),
+ * w_dgrad as packed above; dy gated by act'(y) when y != NULL.  `workspace` holds
+ * wu_conv3x3_s2_dgrad_workspace() bytes (the zero-upsampled gradient). */
+size_t wu_conv3x3_s2_dgrad_workspace(int N, int H, int W, int Cout, int dtype);
+int wu_conv3x3_s2_dgrad(const void* dy, int lddy, const void* y, int ldy_, int act, const void* w_dgrad,
+                        void* dx, int lddx, void* workspace, size_t workspace_bytes,
+                        int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+
+/* ---- thin layers (HBM-bound, no MFMA) -------------------------------------------------------
+ * First conv of dconv_down1 / of the discriminator: Cin = 3 read straight from the NCHW fp32
+ * image (cunet.py:45 via nets.py:20; disc.py:28 via nets.py:28-31).
+ * out_nchw == 0: y is NHWC `dtype` with ld=ldy (Cout % 8 == 0);  out_nchw != 0: y is NCHW fp32
+ * (the 3->3 SN conv of disc.conv1[0]).  w is OIHW fp32 (Cout,3,3,3) scaled by *inv_sigma if given. */
+int wu_conv3x3_c3_fwd(const float* x_nchw, const float* w_oihw, const float* bias, const float* inv_sigma,
+                      void* y, int ldy, int out_nchw, int N, int H, int W, int Cout, int stride, int act,
+                      int dtype, void* stream);
+/* its weight/bias gradient (the image needs no data gradient in the generator); dy NHWC or NCHW fp32 */
+int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy, int dy_nchw, const void* y, int ldy_,
+                        int act, float* dw_oihw, float* dbias, int N, int H, int W, int Cout, int stride,
+                        int accumulate, int dtype, void* stream);
+/* data gradient wrt the NCHW fp32 image (needed when D is differentiated wrt G's output,
+ * t_cls_train.py:243,272): dx_nchw (N,3,H,W) fp32. */
+int wu_conv3x3_c3_dgrad(const void* dy, int lddy, int dy_nchw, const void* y, int ldy_, int act,
+                        const float* w_oihw, const float* inv_sigma, float* dx_nchw, int N, int H, int W,
+                        int Cout, int stride, int accumulate, int dtype, void* stream);
+
+/* conv_last + Tanh (cunet.py:39-40,80-82): out_nchw (N,3,H,W) fp32 = tanh(W x + b),
+ * x NHWC (N,H,W,Cin) ld=ldx, w (3,Cin) fp32. */
+int wu_conv1x1_tanh_fwd(const void* x, int ldx, const float* w, const float* bias, float* out_nchw,
+                        int N, int H, int W, int Cin, int dtype, void* stream);
+/* backward: g = dout*(1-out^2); dx = W^T g (NHWC ld=lddx); dw (+)= g x^T; dbias (+)= sum g. */
+int wu_conv1x1_tanh_bwd(const float* dout_nchw, const float* out_nchw, const void* x, int ldx, const float* w,
+                        void* dx, int lddx, float* dw, float* dbias, int N, int H, int W, int Cin,
+                        int accumulate, int dtype, void* stream);
+
+/* ---- glue ------------------------------------------------------------------------------------
+ * nn.MaxPool2d(2) (cunet.py:27; calls :46,49,52).  x (N,H,W,C) -> y (N,H/2,W/2,C). */
+int wu_maxpool2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, void* stream);
+/* dx = route(dy to the first arg-max of each window, PyTorch's tie rule) [+ dskip]:
+ * `dskip` (may be NULL, ld=lddskip) is the gradient arriving over the skip connection of the same
+ * tensor (cunet.py:62,69,76), summed here instead of by a separate autograd add. */
+int wu_maxpool2_bwd(const void* x, int ldx, const void* dy, int lddy, const void* dskip, int lddskip,
+                    void* dx, int lddx, int N, int H, int W, int C, int dtype, void* stream);
+
+/* AdaIN instance statistics (utils.py:34-39,47): per (n,c) over H*W: stats[n][c] = {mean, rstd}
+ * with rstd = 1/sqrt(unbiased_var + eps).  `scratch` holds N*C*2 floats (zeroed by the call). */
+int wu_adain_stats(const void* x, int ldx, float* stats, float* scratch, int N, int H, int W, int C,
+                   float eps, int dtype, void* stream);
+
+/* Fused AdaIN-apply (utils.py:49-50) -> bilinear x2 align_corners=True (cunet.py:26,60,67,74) ->
+ * Dropout(p) (cunet.py:28,61,68,75) written into channels [0,C) of the concat buffer `y`
+ * (N,2H,2W,*) ld=ldy; the skip tensor already lives in channels [C, ...) (torch.cat, cunet.py:62).
+ * y_std / y_mean: (N,C) fp32 style statistics of utils.py:46,48.  p_drop == 0 -> eval mode.
+ * Dropout keep-mask = counter RNG(seed, element index); keep scale 1/(1-p). */
+int wu_adain_upcat_fwd(const void* x, int ldx, const float* stats, const float* y_std, const float* y_mean,
+                       void* y, int ldy, int N, int H, int W, int C, float p_drop, uint64_t seed,
+                       int dtype, void* stream);
+/* Backward of the above.  dy: gradient of the concat buffer channels [0,C) (N,2H,2W) ld=lddy.
+ * Produces dx (N,H,W,C) ld=lddx and d_y_std, d_y_mean (N,C) fp32.  `gtmp` (N*H*W*C floats) and
+ * `sums` (N*C*2 floats) are caller-provided scratch. */
+int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int ldx, const float* stats, const float* y_std,
+                       void* dx, int lddx, float* d_y_std, float* d_y_mean, float* gtmp, float* sums,
+                       int N, int H, int W, int C, float p_drop, uint64_t seed, int dtype, void* stream);
+/* The keep-mask wu_adain_upcat_fwd draws for (seed, p): mask[n][c][h2][w2] (NCHW uint8), for tests. */
+int wu_dropout_mask(uint8_t* mask_nchw, int N, int H2, int W2, int C, float p_drop, uint64_t seed, void* stream);
+
+/* Discriminator head (disc.py:32): feat[n][c] = sum_{h,w} x[n,h,w,c]  (fp32), and its backward
+ * dx[n,h,w,c] = dfeat[n][c]. */
+int wu_sumpool_fwd(const void* x, int ldx, float* feat, int N, int H, int W, int C, int dtype, void* stream);
+int wu_sumpool_bwd(const float* dfeat, void* dx, int lddx, int N, int H, int W, int C, int dtype, void* stream);
+
+/* layout helpers for the module boundary: NHWC `dtype` <-> NCHW fp32 (feature maps returned by
+ * SNDisc.forward, disc.py:38; gradients flowing back into them). */
+int wu_nhwc_to_nchw_f32(const void* x, int ldx, float* y_nchw, int N, int H, int W, int C, int dtype, void* stream);
+int wu_nchw_f32_to_nhwc(const float* x_nchw, void* y, int ldy, int N, int H, int W, int C, int dtype, void* stream);
+
+/* ---- instrumentation (bench.py roofline leg) -------------------------------------------------
+ * When enabled, the launchers of kernel family `family` bracket each launch with hipEvents on the
+ * launch stream (events from a fixed pool, no allocation after wu_prof_begin).  wu_prof_end
+ * synchronises those events and returns launches / total ms / total algorithmic flops / bytes. */
+#define WU_FAM_CONV_MFMA 1
+#define WU_FAM_WGRAD 2
+#define WU_FAM_ALL 255
+int wu_prof_begin(int family, int max_launches);
+int wu_prof_end(int* launches, double* total_ms, double* total_flops, double* total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,287 @@
+"""GPU parity of every HIP kernel against stock-PyTorch CPU fp32 (the oracle's arithmetic), through the
+C ABI (ctypes -> libwu_kernels.so).  fp32 kernels: tight tolerances (exact-fp32 MFMA, only the summation
+order differs).  bf16 kernels: the reference is evaluated on bf16-ROUNDED inputs/weights, so what remains
+is accumulation order + one output rounding (2^-9 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = ["fp32", "bf16"]
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _tdt(p):
+    return torch.float32 if p == "fp32" else torch.bfloat16
+
+
+def _round(t, p):
+    return t.to(_tdt(p)).float()
+
+
+def _tol(p, ref, k=1.0):
+    scale = max(1.0, float(ref.abs().max()))
+    return (2e-4 if p == "fp32" else 1.2e-2) * scale * k
+
+
+def _rand(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g) * (hi - lo) + lo
+
+
+def _nhwc(x_cpu, p):
+    from wu.layout import as_nhwc, precision_code
+    return as_nhwc(x_cpu.to(_dev()), precision_code(p))
+
+
+CONV_SHAPES = [
+    # N, Cin, Cout, H, W, stride
+    (2, 64, 64, 16, 32, 1),
+    (1, 64, 128, 24, 40, 1),      # ragged: H, W not multiples of the 8x32 tile
+    (2, 192, 64, 8, 8, 1),        # narrow image -> TW = 8 tiles; concat-sized Cin
+    (1, 128, 128, 4, 4, 1),       # 4x4 bottleneck of a 32x32 input
+    (3, 64, 64, 33, 35, 1),       # odd sizes
+    (2, 64, 128, 16, 32, 2),      # discriminator stride-2
+    (1, 128, 64, 10, 12, 2),
+]
+
+
+@pytest.mark.parametrize("p", DTYPES)
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_conv3x3_forward(p, shape, act):
+    from wu import functional as WF
+    n, cin, cout, h, w, stride = shape
+    if act == 2 and stride == 1 and cin != 64:
+        pytest.skip("leaky covered on a subset")
+    x = _round(_rand((n, cin, h, w), 1), p)
+    wt = _round(_rand((cout, cin, 3, 3), 2, -0.1, 0.1), p)
+    b = _rand((cout,), 3)
+    ref = F.conv2d(x, wt, b, stride=stride, padding=1)
+    ref = {0: ref, 1: F.relu(ref), 2: F.leaky_relu(ref, 0.2)}[act]
+    y = WF.conv3x3(_nhwc(x, p), wt.to(_dev()), b.to(_dev()), WF.PackedConv(), stride, act)
+    assert y.shape == ref.shape
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err <= _tol(p, ref), f"max-abs {err}"
+
+
+@pytest.mark.parametrize("p", DTYPES)
+def test_conv3x3_into_concat_slice(p):
+    """Output written into a channel slice of a wider NHWC buffer (the zero-copy torch.cat, cunet.py:62)."""
+    from wu import functional as WF
+    from wu.layout import empty_nhwc
+    n, cin, cout, h, w = 2, 64, 64, 16, 32
+    x = _round(_rand((n, cin, h, w), 4), p)
+    wt = _round(_rand((cout, cin, 3, 3), 5, -0.1, 0.1), p)
+    b = _rand((cout,), 6)
+    ref = F.relu(F.conv2d(x, wt, b, padding=1))
+    cat = empty_nhwc(n, 128 + cout, h, w, _tdt(p), _dev())
+    cat.fill_(7.0)
+    y = WF.conv3x3(_nhwc(x, p), wt.to(_dev()), b.to(_dev()), WF.PackedConv(), 1, 1, cat[:, 128:])
+    assert y.data_ptr() == cat[:, 128:].data_ptr()
+    assert (cat[:, 128:].float().cpu() - ref).abs().max().item() <= _tol(p, ref)
+    assert (cat[:, :128].float() == 7.0).all()       # neighbours untouched
+    # and read back as a strided input
+    y2 = WF.conv3x3(cat[:, 128:], wt.to(_dev()), b.to(_dev()), WF.PackedConv(), 1, 0)
+    ref2 = F.conv2d(_round(ref, p), wt, b, padding=1)
+    assert (y2.float().cpu() - ref2).abs().max().item() <= _tol(p, ref2, 2.0)
+
+
+@pytest.mark.parametrize("p", DTYPES)
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_conv3x3_backward(p, shape, act):
+    """dgrad (gated-input MFMA pass / zero-upsampled stride-2 pass) and wgrad (transposed-LDS-read MFMA +
+    deterministic split-K) against torch autograd on CPU."""
+    from wu import functional as WF
+    n, cin, cout, h, w, stride = shape
+    if act == 2 and cin != 64:
+        pytest.skip("leaky covered on a subset")
+    x = _round(_rand((n, cin, h, w), 11), p).requires_grad_(True)
+    wt = _round(_rand((cout, cin, 3, 3), 12, -0.1, 0.1), p).requires_grad_(True)
+    b = _rand((cout,), 13).requires_grad_(True)
+    pre = F.conv2d(x, wt, b, stride=stride, padding=1)
+    ref = {0: pre, 1: F.relu(pre), 2: F.leaky_relu(pre, 0.2)}[act]
+    gy = _round(_rand(tuple(ref.shape), 14), p)
+    # the kernel gates on the STORED (rounded) output; make the reference gate identically
+    ref.backward(gy)
+    xg = _nhwc(x.detach(), p).requires_grad_(True)
+    wg = wt.detach().to(_dev()).requires_grad_(True)
+    bg = b.detach().to(_dev()).requires_grad_(True)
+    y = WF.conv3x3(xg, wg, bg, WF.PackedConv(), stride, act)
+    y.backward(_nhwc(gy, p))
+    for name, got, want, k in (("dx", xg.grad, x.grad, 1.0), ("dw", wg.grad, wt.grad, 4.0), ("db", bg.grad, b.grad, 4.0)):
+        err = (got.float().cpu() - want).abs().max().item()
+        tol = _tol(p, want, k)
+        if name != "dx" and p == "bf16":
+            tol = 2e-3 * float(want.abs().max()) + 1e-3     # fp32-accumulated: tighter than the bf16-stored dx
+        assert err <= tol, f"{name}: max-abs {err} (tol {tol}, |ref|max {want.abs().max().item()})"
+
+
+@pytest.mark.parametrize("p", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 64, 16, 24, 1, 1, False), (2, 64, 17, 19, 2, 2, False), (2, 3, 12, 20, 1, 0, True)])
+def test_conv3x3_c3(p, cfg):
+    """3-input-channel conv read from the NCHW fp32 image (cunet.py:45, disc.py:28): fwd, wgrad, dgrad."""
+    from wu import functional as WF
+    from wu.layout import precision_code
+    n, cout, h, w, stride, act, out_nchw = cfg
+    x = _rand((n, 3, h, w), 21).requires_grad_(True)
+    wt = _rand((cout, 3, 3, 3), 22, -0.3, 0.3).requires_grad_(True)
+    b = _rand((cout,), 23).requires_grad_(True)
+    pre = F.conv2d(x, wt, b, stride=stride, padding=1)
+    ref = {0: pre, 1: F.relu(pre), 2: F.leaky_relu(pre, 0.2)}[act]
+    gy = _round(_rand(tuple(ref.shape), 24), "fp32" if out_nchw else p)
+    ref.backward(gy)
+    xg = x.detach().to(_dev()).requires_grad_(True)
+    wg = wt.detach().to(_dev()).requires_grad_(True)
+    bg = b.detach().to(_dev()).requires_grad_(True)
+    y = WF.conv3x3_c3(xg, wg, bg, stride, act, out_nchw, precision_code(p))
+    pp = "fp32" if out_nchw else p
+    assert (y.float().cpu() - ref.detach()).abs().max().item() <= _tol(pp, ref.detach())
+    y.backward(gy.to(_dev()) if out_nchw else _nhwc(gy, p))
+    # gating uses the stored (rounded) activations: compare with a loose-but-meaningful tolerance
+    for name, got, want in (("dx", xg.grad, x.grad), ("dw", wg.grad, wt.grad), ("db", bg.grad, b.grad)):
+        err = (got.float().cpu() - want).abs().max().item()
+        assert err <= (2e-3 if pp == "bf16" else 2e-4) * max(1.0, float(want.abs().max())), f"{name}: {err}"
+
+
+@pytest.mark.parametrize("p", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 64, 16, 32), (1, 128, 6, 10), (3, 256, 4, 4)])
+def test_maxpool(p, shape):
+    from wu import functional as WF
+    n, c, h, w = shape
+    x = _round(_rand((n, c, h, w), 31), p)
+    # force ties (bf16-like plateaus) so the first-max tie rule is exercised
+    x = (x * 4).round() / 4
+    x.requires_grad_(True)
+    ref = F.max_pool2d(x, 2)
+    gy = _round(_rand(tuple(ref.shape), 32), p)
+    ref.backward(gy)
+    xg = _nhwc(x.detach(), p).requires_grad_(True)
+    y = WF.maxpool2(xg)
+    assert torch.equal(y.float().cpu(), ref.detach())
+    y.backward(_nhwc(gy, p))
+    assert torch.equal(xg.grad.float().cpu(), x.grad)
+
+
+@pytest.mark.parametrize("p", DTYPES)
+def test_maxpool_bwd_fused_skip(p):
+    """C ABI: dx = route(dy) + dskip in one pass (the encoder's two-consumer gradient sum)."""
+    from wu import _lib
+    from wu.layout import empty_nhwc, nhwc_ld, precision_code, stream_ptr
+    n, c, h, w = 2, 64, 8, 16
+    x = _round(_rand((n, c, h, w), 33), p).requires_grad_(True)
+    ref = F.max_pool2d(x, 2)
+    gy = _round(_rand(tuple(ref.shape), 34), p)
+    gs = _round(_rand((n, c, h, w), 35), p)
+    ref.backward(gy)
+    want = x.grad + gs
+    xd, gyd, gsd = _nhwc(x.detach(), p), _nhwc(gy, p), _nhwc(gs, p)
+    dx = empty_nhwc(n, c, h, w, _tdt(p), _dev())
+    _lib.call("wu_maxpool2_bwd", xd.data_ptr(), nhwc_ld(xd), gyd.data_ptr(), nhwc_ld(gyd), gsd.data_ptr(), nhwc_ld(gsd),
+              dx.data_ptr(), nhwc_ld(dx), n, h, w, c, precision_code(p), stream_ptr())
+    assert (dx.float().cpu() - want).abs().max().item() <= (1e-6 if p == "fp32" else 1.6e-2)
+
+
+def _adain_upcat_ref(x, c_std, c_mean, skip, eps, mask):
+    n, c = x.shape[:2]
+    xf = x.reshape(n, c, -1)
+    x_std = (xf.var(dim=-1) + eps).sqrt().view(n, c, 1, 1)
+    x_mean = xf.mean(dim=-1).view(n, c, 1, 1)
+    y = (x - x_mean) / x_std * c_std.view(n, c, 1, 1) + c_mean.view(n, c, 1, 1)
+    y = F.interpolate(y, scale_factor=2, mode="bilinear", align_corners=True)
+    if mask is not None:
+        y = y * mask / 0.7
+    return torch.cat([y, skip], dim=1)
+
+
+@pytest.mark.parametrize("p", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 128, 8, 8, 64), (1, 256, 4, 6, 128), (2, 64, 16, 16, 64)])
+@pytest.mark.parametrize("train", [False, True])
+def test_adain_upcat(p, shape, train):
+    """AdaIN (utils.py:41-51) -> bilinear x2 align_corners (cunet.py:26) -> Dropout(0.3) -> cat, fused; forward
+    and backward (dx, d y_std, d y_mean, d skip).  Train mode: the oracle gets the kernel's own keep-mask."""
+    from wu import functional as WF
+    from wu.layout import empty_nhwc
+    n, c, h, w, cs = shape
+    eps = 1e-5
+    x = _round(_rand((n, c, h, w), 41, -1, 2), p).requires_grad_(True)
+    ystd = _rand((n, c), 42, 0.5, 1.5).requires_grad_(True)
+    ymean = _rand((n, c), 43).requires_grad_(True)
+    skip = _round(_rand((n, cs, 2 * h, 2 * w), 44), p).requires_grad_(True)
+    seed = 1234567
+    mask = WF.dropout_mask(n, c, 2 * h, 2 * w, 0.3, seed, _dev()).float().cpu() if train else None
+    if train:
+        assert abs(mask.mean().item() - 0.7) < 0.02
+    ref = _adain_upcat_ref(x, ystd, ymean, skip, eps, mask)
+    g = _round(_rand(tuple(ref.shape), 45), p)
+    ref.backward(g)
+
+    xg = _nhwc(x.detach(), p).requires_grad_(True)
+    sg, mg = ystd.detach().to(_dev()).requires_grad_(True), ymean.detach().to(_dev()).requires_grad_(True)
+    cat = empty_nhwc(n, c + cs, 2 * h, 2 * w, _tdt(p), _dev())
+    cat[:, c:].copy_(skip.detach().to(_dev()))
+    skg = cat[:, c:].detach().requires_grad_(True)
+    out = WF.adain_upcat(xg, sg, mg, skg, cat, eps, 0.3 if train else 0.0, seed)
+    err = (out.float().cpu() - ref.detach()).abs().max().item()
+    assert err <= _tol(p, ref.detach(), 2.0), f"fwd {err}"
+    out.backward(_nhwc(g, p))
+    k = {"fp32": 2e-4, "bf16": 3e-2}[p]
+    for name, got, want in (("dx", xg.grad, x.grad), ("dstd", sg.grad, ystd.grad), ("dmean", mg.grad, ymean.grad), ("dskip", skg.grad, skip.grad)):
+        err = (got.float().cpu() - want).abs().max().item()
+        assert err <= k * max(1.0, float(want.abs().max())), f"{name}: {err} vs |ref| {want.abs().max().item()}"
+
+
+@pytest.mark.parametrize("p", DTYPES)
+def test_conv1x1_tanh(p):
+    from wu import functional as WF
+    n, cin, h, w = 2, 64, 12, 20
+    x = _round(_rand((n, cin, h, w), 51), p).requires_grad_(True)
+    wt = _rand((3, cin, 1, 1), 52, -0.3, 0.3).requires_grad_(True)
+    b = _rand((3,), 53).requires_grad_(True)
+    ref = torch.tanh(F.conv2d(x, wt, b))
+    g = _rand(tuple(ref.shape), 54)
+    ref.backward(g)
+    xg = _nhwc(x.detach(), p).requires_grad_(True)
+    wg, bg = wt.detach().to(_dev()).requires_grad_(True), b.detach().to(_dev()).requires_grad_(True)
+    out = WF.conv1x1_tanh(xg, wg, bg)
+    assert out.dtype == torch.float32 and out.is_contiguous()
+    assert (out.cpu() - ref.detach()).abs().max().item() <= 2e-5
+    out.backward(g.to(_dev()))
+    assert (xg.grad.float().cpu() - x.grad).abs().max().item() <= (1e-5 if p == "fp32" else 8e-3)
+    assert (wg.grad.cpu() - wt.grad).abs().max().item() <= 1e-3 * max(1.0, float(wt.grad.abs().max()))
+    assert (bg.grad.cpu() - b.grad).abs().max().item() <= 1e-3 * max(1.0, float(b.grad.abs().max()))
+
+
+@pytest.mark.parametrize("p", DTYPES)
+def test_sumpool_and_layout(p):
+    from wu import functional as WF
+    from wu.layout import to_nchw_f32
+    n, c, h, w = 2, 128, 5, 7
+    x = _round(_rand((n, c, h, w), 61), p).requires_grad_(True)
+    ref = x.sum(dim=[2, 3])
+    g = _rand((n, c), 62)
+    ref.backward(g)
+    xg = _nhwc(x.detach(), p).requires_grad_(True)
+    assert torch.equal(to_nchw_f32(xg.detach()).cpu(), x.detach())       # NHWC <-> NCHW round trip is exact
+    f = WF.sumpool(xg)
+    assert (f.cpu() - ref.detach()).abs().max().item() <= 1e-4
+    f.backward(g.to(_dev()))
+    assert (xg.grad.float().cpu() - x.grad).abs().max().item() <= (0 if p == "fp32" else 4e-3)
+
+
+def test_rejects_bad_arguments():
+    """Error behaviour of the boundary: shape/alignment violations come back as RuntimeError, CPU tensors are
+    refused (no fallback)."""
+    from wu import functional as WF
+    x = torch.zeros(1, 48, 8, 8, device=_dev()).contiguous(memory_format=torch.channels_last)
+    with pytest.raises(RuntimeError, match="Cin"):
+        WF.conv3x3(x, torch.zeros(64, 48, 3, 3, device=_dev()), None, WF.PackedConv(), 1, 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        WF.maxpool2(torch.zeros(1, 64, 8, 8))

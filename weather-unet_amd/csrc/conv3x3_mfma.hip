@@ -1,0 +1,324 @@
+// conv3x3 (pad 1, stride 1|2) as an im2col-free implicit GEMM on the CDNA4 matrix cores.
+//
+// Replaces nn.Conv2d(cin, cout, 3, padding=1[, stride=2]) + ReLU / LeakyReLU of the reference's
+// r_double_conv / sn_double_conv (nets.py:18-33); with the rotated/transposed weight pack and a gated
+// input it is also the data-gradient pass of the same convs.
+//
+// GEMM view: M = output pixels, N = Cout, K = 9 * Cin.  One 256-thread workgroup (4 waves, one per
+// SIMD) owns a TH x TW tile of 256 output pixels x 64 output channels; each wave owns 64 pixels x 64
+// channels as 2x2 accumulators of v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32 (fp32).
+// Per 64-byte channel chunk (32 bf16 / 16 fp32 channels) the input HALO tile ((TH+2) x (TW+2) pixels)
+// and the [9][64][chunk] weight slab are staged once into LDS and re-used by all nine taps: the tap
+// shift is an LDS address offset, so no im2col tensor ever exists.  Global -> register -> LDS staging
+// of chunk k+1 is issued before the MFMAs of chunk k (loads in flight under the matrix work); with
+// <= 64 KiB of LDS two workgroups share a CU and cover each other's barriers.
+//
+// LDS images: pixel-major, 64 B per pixel (one chunk), the four 16-B slots of a pixel XOR-swizzled
+// with (pixel >> 2) & 3 so a ds_read_b128 lane group touches 16 distinct slots (conflict-free for
+// TW = 32).  Same for the weight rows ([tap][cout] rows of 64 B).
+#include "wu_common.h"
+
+#define WU_REP9(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8)
+
+namespace {
+
+constexpr int kTilePix = 256;   // output pixels per workgroup
+constexpr int kBN = 64;         // output channels per workgroup
+constexpr int kChunkBytes = 64; // channel chunk per pixel in LDS
+
+struct ConvArgs {
+    const void* x;
+    const void* mask;
+    const void* w;
+    const float* bias;
+    void* y;
+    int ldx, ldmask, ldy;
+    int N, H, W, Ho, Wo, Cin, Cout;
+    int act, mask_act;
+    int tw_log2;      // tile width  = 1 << tw_log2  (output pixels)
+    int tiles_x, tiles_y, cout_tiles;
+    int halo_w, halo_h, halo_pix;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // exact-fp32 MFMA: lane half h of a 16-B chunk supplies k = 4h+j to the j-th 32x32x2 step; A and B use
+    // the same k permutation, so the sum over the 8 channels of the chunk pair is complete.
+    static __device__ __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int swz_off(int row, int slot) { return row * kChunkBytes + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+template <typename T, int STRIDE, bool MASKED, int NHALO>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int kChunkElems = kChunkBytes / (int)sizeof(T);
+    char* halo_lds = smem;
+    char* w_lds = smem + a.halo_pix * kChunkBytes;  // halo_pix*64 is a multiple of 16
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- which tile ----
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = bid % a.cout_tiles; bid /= a.cout_tiles;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+    const int n = bid;
+    const int TW = 1 << a.tw_log2, TH = kTilePix >> a.tw_log2;
+    const int oh0 = ty * TH, ow0 = tx * TW;        // output tile origin
+    const int ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;  // input halo origin
+    const int co0 = ct * kBN;
+
+    const T* xin = (const T*)a.x + (size_t)n * a.H * a.W * a.ldx;
+    const T* xmask = MASKED ? (const T*)a.mask + (size_t)n * a.H * a.W * a.ldmask : nullptr;
+
+    // ---- per-thread staging descriptors: item = (halo pixel, 16-B slot) ----
+    int hoff[NHALO];   // element offset of the pixel inside image n (-1: zero fill / unused)
+    int moff[MASKED ? NHALO : 1];
+    int hdst[NHALO];   // LDS byte offset
+#pragma unroll
+    for (int k = 0; k < NHALO; ++k) {
+        const int item = tid + 256 * k;
+        const int p = item >> 2, slot = item & 3;
+        hoff[k] = -1;
+        hdst[k] = -1;
+        if (MASKED) moff[k] = -1;
+        if (p < a.halo_pix) {
+            const int hy = p / a.halo_w, hx = p - hy * a.halo_w;
+            const int ih = ih0 + hy, iw = iw0 + hx;
+            hdst[k] = swz_off(p, slot);
+            if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+                hoff[k] = (ih * a.W + iw) * a.ldx + slot * (16 / (int)sizeof(T));
+                if (MASKED) moff[k] = (ih * a.W + iw) * a.ldmask + slot * (16 / (int)sizeof(T));
+            }
+        }
+    }
+    // weights: thread -> (cout row tid>>2, slot tid&3) for each of the 9 taps
+    const int wrow = tid >> 2, wslot = tid & 3;
+    const T* wsrc = (const T*)a.w + (size_t)(co0 + wrow) * a.Cin + wslot * (16 / (int)sizeof(T));
+    const size_t wtap_stride = (size_t)a.Cout * a.Cin;
+    const int wdst = swz_off(wrow, wslot);
+
+    // ---- per-lane fragment addresses ----
+    // A: wave owns tile pixels [64*wave, 64*wave+64): two 32-row groups mi; row r -> (ty_, tx_) in the tile
+    int apix[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int r = 64 * wave + 32 * mi + l31;
+        const int ry = r >> a.tw_log2, rx = r & (TW - 1);
+        apix[mi] = (ry * STRIDE) * a.halo_w + rx * STRIDE;
+    }
+    int boff[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) boff[ni] = swz_off(32 * ni + l31, lh);
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+    uint4 hreg[NHALO];
+    uint4 wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7, wr8;   // named (not an array): keeps them out of scratch
+    uint4 mreg[MASKED ? NHALO : 1];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    auto load_chunk = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NHALO; ++k) {
+            hreg[k] = zero4;
+            if (hoff[k] >= 0) hreg[k] = *(const uint4*)(xin + hoff[k] + c0);
+            if (MASKED) {
+                mreg[k] = zero4;
+                if (moff[k] >= 0) mreg[k] = *(const uint4*)(xmask + moff[k] + c0);
+            }
+        }
+#define WU_LOADW(t) wr##t = *(const uint4*)(wsrc + (t) * wtap_stride + c0);
+        WU_REP9(WU_LOADW)
+#undef WU_LOADW
+    };
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NHALO; ++k) {
+            if (hdst[k] >= 0) {
+                uint4 v = hreg[k];
+                if (MASKED) v = gate16<T>(v, mreg[k], a.mask_act);
+                *(uint4*)(halo_lds + hdst[k]) = v;
+            }
+        }
+#define WU_STOREW(t) *(uint4*)(w_lds + (t) * (kBN * kChunkBytes) + wdst) = wr##t;
+        WU_REP9(WU_STOREW)
+#undef WU_STOREW
+    };
+
+    // stride-2 tiles have a 4x larger halo: staged global -> LDS directly (no register prefetch)
+    auto stage_direct = [&](int c0) __attribute__((always_inline)) {
+        for (int item = tid; item < a.halo_pix * 4; item += 256) {
+            const int p = item >> 2, slot = item & 3;
+            const int hy = p / a.halo_w, hx = p - hy * a.halo_w;
+            const int ih = ih0 + hy, iw = iw0 + hx;
+            uint4 v = zero4;
+            if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+                v = *(const uint4*)(xin + (size_t)(ih * a.W + iw) * a.ldx + slot * (16 / (int)sizeof(T)) + c0);
+            *(uint4*)(halo_lds + swz_off(p, slot)) = v;
+        }
+#define WU_COPYW(t) *(uint4*)(w_lds + (t) * (kBN * kChunkBytes) + wdst) = *(const uint4*)(wsrc + (t) * wtap_stride + c0);
+        WU_REP9(WU_COPYW)
+#undef WU_COPYW
+    };
+
+    const int nchunks = a.Cin / kChunkElems;
+    if constexpr (STRIDE == 1) {
+        load_chunk(0);
+        store_chunk();
+        __syncthreads();
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        if constexpr (STRIDE == 1) {
+            if (c + 1 < nchunks) load_chunk((c + 1) * kChunkElems);
+        } else {
+            stage_direct(c * kChunkElems);
+            __syncthreads();
+        }
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int tap = kh * 3 + kw;
+            int aoff[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) aoff[mi] = swz_off(apix[mi] + kh * a.halo_w + kw, lh);
+            const char* wt = w_lds + tap * (kBN * kChunkBytes);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 af[2], bf[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) af[mi] = *(const uint4*)(halo_lds + (aoff[mi] ^ (ks << 5)));
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) bf[ni] = *(const uint4*)(wt + (boff[ni] ^ (ks << 5)));
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) Mma<T>::run(acc[mi][ni], af[mi], bf[ni]);
+            }
+        }
+        __syncthreads();
+        if constexpr (STRIDE == 1) {
+            if (c + 1 < nchunks) {
+                store_chunk();
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: bias + activation in fp32, transpose through LDS, 16-B coalesced stores ----
+    // LDS image [256 pixels][64 cout] of T, row stride 64*sizeof(T) + 16 B pad
+    constexpr int kRow = kBN * (int)sizeof(T) + 16;
+    float bv[2] = {0.f, 0.f};
+    if (a.bias) {
+        bv[0] = a.bias[co0 + l31];
+        bv[1] = a.bias[co0 + 32 + l31];
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 64 * wave + 32 * mi + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                const float v = act_apply(acc[mi][ni][i] + bv[ni], a.act);
+                ElemTraits<T>::store((T*)(smem + row * kRow) + 32 * ni + l31, v);
+            }
+    __syncthreads();
+    constexpr int kSlotsPerRow = kBN * (int)sizeof(T) / 16;  // 8 (bf16) / 16 (fp32)
+    T* yout = (T*)a.y + (size_t)n * a.Ho * a.Wo * a.ldy + co0;
+#pragma unroll
+    for (int k = 0; k < kTilePix * kSlotsPerRow / 256; ++k) {
+        const int q = tid + 256 * k;
+        const int r = q / kSlotsPerRow, s = q % kSlotsPerRow;
+        const int oh = oh0 + (r >> a.tw_log2), ow = ow0 + (r & (TW - 1));
+        if (oh < a.Ho && ow < a.Wo) {
+            const uint4 v = *(const uint4*)(smem + r * kRow + s * 16);
+            *(uint4*)(yout + (size_t)(oh * a.Wo + ow) * a.ldy + s * (16 / (int)sizeof(T))) = v;
+        }
+    }
+}
+
+template <typename T, int STRIDE, bool MASKED>
+int launch_conv(const ConvArgs& a, size_t lds_bytes, int grid, hipStream_t s) {
+    constexpr int NH = STRIDE == 1 ? 7 : 1;   // stride 2 stages without per-thread descriptors
+    auto kern = conv3x3_mfma_kernel<T, STRIDE, MASKED, NH>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, s, a);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                              int N, int H, int W, int Cin, int Cout, int stride, int act,
+                              const void* mask, int ldmask, int mask_act, int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    const int chunk = kChunkBytes / esz;
+    WU_REQUIRE(dtype == WU_F32 || dtype == WU_BF16, "conv3x3_fwd: bad dtype %d", dtype);
+    WU_REQUIRE(stride == 1 || stride == 2, "conv3x3_fwd: stride %d", stride);
+    WU_REQUIRE(N > 0 && H > 0 && W > 0, "conv3x3_fwd: empty shape");
+    WU_REQUIRE(Cin % chunk == 0 && Cin > 0, "conv3x3_fwd: Cin=%d must be a multiple of %d", Cin, chunk);
+    WU_REQUIRE(Cout % kBN == 0 && Cout > 0, "conv3x3_fwd: Cout=%d must be a multiple of %d", Cout, kBN);
+    WU_REQUIRE(ldx >= Cin && ldy >= Cout && (ldx * esz) % 16 == 0 && (ldy * esz) % 16 == 0, "conv3x3_fwd: bad ld (%d,%d)", ldx, ldy);
+    WU_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)w_packed % 16) == 0, "conv3x3_fwd: pointers must be 16-B aligned");
+    WU_REQUIRE((size_t)H * W * (size_t)(ldx > ldmask ? ldx : ldmask) < (1ull << 31), "conv3x3_fwd: image too large for 32-bit offsets");
+    if (mask) WU_REQUIRE(stride == 1 && ldmask >= Cin && (ldmask * esz) % 16 == 0 && ((uintptr_t)mask % 16) == 0, "conv3x3_fwd: bad mask");
+
+    ConvArgs a;
+    a.x = x; a.mask = mask; a.w = w_packed; a.bias = bias; a.y = y;
+    a.ldx = ldx; a.ldmask = ldmask; a.ldy = ldy;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
+    a.act = act; a.mask_act = mask_act;
+    int twl = 5;
+    while (twl > 2 && (1 << (twl - 1)) >= a.Wo) --twl;   // narrow images: TW = 16 / 8 / 4
+    a.tw_log2 = twl;
+    const int TW = 1 << twl, TH = kTilePix >> twl;
+    a.tiles_x = cdiv(a.Wo, TW); a.tiles_y = cdiv(a.Ho, TH); a.cout_tiles = Cout / kBN;
+    a.halo_w = (TW - 1) * stride + 3; a.halo_h = (TH - 1) * stride + 3;
+    a.halo_pix = a.halo_w * a.halo_h;
+    if (stride == 1) WU_REQUIRE(a.halo_pix <= 7 * 256 / 4, "conv3x3_fwd: halo %d exceeds staging capacity", a.halo_pix);
+    size_t lds = (size_t)a.halo_pix * kChunkBytes + 9 * kBN * kChunkBytes;
+    const size_t epi = (size_t)kTilePix * (kBN * esz + 16);
+    if (epi > lds) lds = epi;
+    const long long grid = (long long)N * a.tiles_x * a.tiles_y * a.cout_tiles;
+    WU_REQUIRE(grid < (1ll << 31), "conv3x3_fwd: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    wu_prof_pre(WU_FAM_CONV_MFMA, s);
+    const bool m = mask != nullptr;
+    if (dtype == WU_BF16) {
+        if (stride == 1) { if (m) launch_conv<bf16_t, 1, true>(a, lds, (int)grid, s); else launch_conv<bf16_t, 1, false>(a, lds, (int)grid, s); }
+        else launch_conv<bf16_t, 2, false>(a, lds, (int)grid, s);
+    } else {
+        if (stride == 1) { if (m) launch_conv<float, 1, true>(a, lds, (int)grid, s); else launch_conv<float, 1, false>(a, lds, (int)grid, s); }
+        else launch_conv<float, 2, false>(a, lds, (int)grid, s);
+    }
+    const double pix = (double)N * a.Ho * a.Wo;
+    wu_prof_post(WU_FAM_CONV_MFMA, s, 2.0 * pix * Cout * 9.0 * Cin,
+                 ((double)N * H * W * Cin * (m ? 2 : 1) + pix * Cout) * esz + 9.0 * Cin * Cout * esz);
+    WU_LAUNCH_CHECK("conv3x3_mfma");
+    return 0;
+}

@@ -1,0 +1,291 @@
+// Weight gradient of conv3x3 (pad 1, stride 1|2) on the matrix cores -- autograd's conv wgrad for the
+// convs of nets.py:18-33 (t_cls_train.py:272,307 call .backward()).
+//
+//   dW[tap][co][ci] = sum over output pixels  dY'[pix][co] * X[pix shifted by tap][ci],   dY' = dY * act'(Y)
+//
+// GEMM view per tap: M = Cout, N = Cin, K = output pixels.  A workgroup (4 waves, 2x2) owns a 64(co) x
+// 64(ci) block for ALL nine taps -- 9 accumulators of 32x32 per wave (144 fp32 registers per lane) -- and
+// walks a strided list of pixel tiles (split-K).  Per tile the dY' tile and the X halo tile are staged
+// once in LDS (pixel-major, as they lie in HBM) and re-used by the nine taps: one dY fragment + nine
+// shifted X fragments per K-step.  The reduction index (pixel) is the slow index of both NHWC operands,
+// so bf16 fragments are fetched with the CDNA4 transposing LDS read ds_read_b64_tr_b16 (4 pixels x 16
+// channels -> column-major), no register shuffles; fp32 fragments are plain ds_read_b32.
+// The 64-B halves of each 128-B pixel row are swapped on odd pixel pairs ((x>>1)&1) so the four pixel
+// rows of a transposed read fall in four disjoint bank ranges.
+// Partial blocks go to per-split slabs; a second kernel sums the slabs in fixed order (deterministic),
+// transposes to OIHW and optionally accumulates into .grad.  dbias rides along (ci-block 0 only).
+#include "wu_common.h"
+
+namespace {
+
+struct WgradArgs {
+    const void* x; const void* dy; const void* y;
+    float* slab;       // [splits][9][Cout][Cin]
+    float* bslab;      // [splits][Cout]
+    int ldx, lddy, ldy;
+    int N, H, W, Ho, Wo, Cin, Cout;
+    int act;
+    int tw_log2, tiles_x, tiles_y, ntiles;   // pixel tiles (over all images)
+    int splits, co_blocks, ci_blocks;
+    int halo_w, halo_h, halo_pix;
+};
+
+template <typename T> struct WTraits;
+template <> struct WTraits<bf16_t> { static constexpr int kRowBytes = 128; static constexpr int kStepPix = 16; };
+template <> struct WTraits<float> { static constexpr int kRowBytes = 256; static constexpr int kStepPix = 2; };
+
+// LDS byte offset of (pixel row `row`, whose x-coordinate inside its image row is `xc`, channel byte `cb`)
+template <typename T> __device__ __forceinline__ int lds_off(int row, int xc, int cb) {
+    if (sizeof(T) == 2) return row * 128 + (cb ^ (((xc >> 1) & 1) << 6));
+    return row * 256 + cb;
+}
+
+template <typename T, int STRIDE, int P>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RB = WTraits<T>::kRowBytes;
+    constexpr int SLOTS = RB / 16;            // 16-B slots per pixel row (64 channels)
+    constexpr int E = 16 / (int)sizeof(T);
+    char* dy_lds = smem;                      // [P][64 co]
+    char* x_lds = smem + P * RB;              // [halo_pix][64 ci]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;  // co / ci quadrant
+    int bid = blockIdx.x;
+    const int split = bid % a.splits; bid /= a.splits;
+    const int cib = bid % a.ci_blocks;
+    const int cob = bid / a.ci_blocks;
+    const int TW = 1 << a.tw_log2, TH = P >> a.tw_log2;
+
+    f32x16_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    float bsum = 0.f;
+
+    for (int tile = split; tile < a.ntiles; tile += a.splits) {
+        int tt = tile;
+        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
+        const int ty = tt % a.tiles_y;
+        const int n = tt / a.tiles_y;
+        const int oh0 = ty * TH, ow0 = tx * TW;
+        const int ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
+
+        // ---- stage dY' tile (gated by act'(Y)) ----
+        {
+            const T* dyb = (const T*)a.dy + (size_t)n * a.Ho * a.Wo * a.lddy + cob * 64;
+            const T* yb = a.y ? (const T*)a.y + (size_t)n * a.Ho * a.Wo * a.ldy + cob * 64 : nullptr;
+            for (int item = tid; item < P * SLOTS; item += 256) {
+                const int r = item / SLOTS, s = item % SLOTS;
+                const int rx = r & (TW - 1), oh = oh0 + (r >> a.tw_log2), ow = ow0 + rx;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (oh < a.Ho && ow < a.Wo) {
+                    const size_t o = (size_t)(oh * a.Wo + ow);
+                    v = *(const uint4*)(dyb + o * a.lddy + s * E);
+                    if (yb) v = gate16<T>(v, *(const uint4*)(yb + o * a.ldy + s * E), a.act);
+                }
+                *(uint4*)(dy_lds + lds_off<T>(r, r, s * 16)) = v;
+            }
+        }
+        // ---- stage X halo tile ----
+        {
+            const T* xb = (const T*)a.x + (size_t)n * a.H * a.W * a.ldx + cib * 64;
+            for (int item = tid; item < a.halo_pix * SLOTS; item += 256) {
+                const int p = item / SLOTS, s = item % SLOTS;
+                const int hy = p / a.halo_w, hx = p - hy * a.halo_w;
+                const int ih = ih0 + hy, iw = iw0 + hx;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = *(const uint4*)(xb + (size_t)(ih * a.W + iw) * a.ldx + s * E);
+                *(uint4*)(x_lds + lds_off<T>(p, hx, s * 16)) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- bias gradient: column sums of the dY' tile (ci-block 0 only) ----
+        if (cib == 0 && a.bslab) {
+            const int co = tid & 63, part = tid >> 6;
+            for (int r = part; r < P; r += 4) bsum += ElemTraits<T>::load((const T*)(dy_lds + lds_off<T>(r, r, co * (int)sizeof(T))));
+        }
+
+        // ---- MFMA over the tile's pixels ----
+        if constexpr (sizeof(T) == 2) {
+            const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+            const int h = g >> 1;
+            const int acb = (32 * wm + 16 * (g & 1) + 4 * pp) * 2;   // channel byte of this lane's A address
+            const int bcb = (32 * wn + 16 * (g & 1) + 4 * pp) * 2;
+#pragma unroll 2
+            for (int ks = 0; ks < P / 16; ++ks) {
+                // this lane addresses tile pixel r0 (first read) and r0 + 4 (second read)
+                const int r0 = 16 * ks + 8 * h + q;
+                s16x4_t a0, a1;
+                {
+                    const int o0 = lds_off<T>(r0, r0, acb), o1 = lds_off<T>(r0 + 4, r0 + 4, acb);
+                    a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(dy_lds + o0));
+                    a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(dy_lds + o1));
+                }
+                const uint4 af = make_uint4(((const uint32_t*)&a0)[0], ((const uint32_t*)&a0)[1], ((const uint32_t*)&a1)[0], ((const uint32_t*)&a1)[1]);
+                int hp[2], hxx[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int r = r0 + 4 * u;
+                    const int ry = r >> a.tw_log2, rx = r & (TW - 1);
+                    hp[u] = ry * STRIDE * a.halo_w + rx * STRIDE;
+                    hxx[u] = rx * STRIDE;
+                }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int kh = tap / 3, kw = tap % 3;
+                    const int o0 = lds_off<T>(hp[0] + kh * a.halo_w + kw, hxx[0] + kw, bcb);
+                    const int o1 = lds_off<T>(hp[1] + kh * a.halo_w + kw, hxx[1] + kw, bcb);
+                    const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(x_lds + o0));
+                    const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(x_lds + o1));
+                    const uint4 bf = make_uint4(((const uint32_t*)&b0)[0], ((const uint32_t*)&b0)[1], ((const uint32_t*)&b1)[0], ((const uint32_t*)&b1)[1]);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bf), acc[tap], 0, 0, 0);
+                }
+            }
+        } else {
+            const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll 2
+            for (int ks = 0; ks < P / 2; ++ks) {
+                const int r = 2 * ks + lh;
+                const float av = *(const float*)(dy_lds + lds_off<T>(r, r, (32 * wm + l31) * 4));
+                const int ry = r >> a.tw_log2, rx = r & (TW - 1);
+                const int hp = ry * STRIDE * a.halo_w + rx * STRIDE;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int kh = tap / 3, kw = tap % 3;
+                    const float bv = *(const float*)(x_lds + lds_off<T>(hp + kh * a.halo_w + kw, 0, (32 * wn + l31) * 4));
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- write the partial block: slab[split][tap][co][ci] ----
+    {
+        const int l31 = lane & 31, lh = lane >> 5;
+        float* sl = a.slab + (size_t)split * 9 * a.Cout * a.Cin;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = cob * 64 + 32 * wm + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                const int ci = cib * 64 + 32 * wn + l31;
+                sl[((size_t)tap * a.Cout + co) * a.Cin + ci] = acc[tap][i];
+            }
+    }
+    if (cib == 0 && a.bslab) {
+        float* red = (float*)smem;     // all waves are past the last tile's barrier
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 64) a.bslab[(size_t)split * a.Cout + cob * 64 + tid] = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
+    }
+}
+
+// sum the split-K slabs in fixed order, transpose [tap][co][ci] -> OIHW, optional accumulate
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab, float* __restrict__ dw,
+                                    float* __restrict__ dbias, int splits, int Cout, int Cin, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = Cout * Cin;
+    if (idx < total) {
+        float s[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s[t] = 0.f;
+        for (int k = 0; k < splits; ++k) {
+            const float* p = slab + (size_t)k * 9 * total + idx;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) s[t] += p[(size_t)t * total];
+        }
+        float* o = dw + (size_t)idx * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o[t] = accumulate ? o[t] + s[t] : s[t];
+    }
+    if (dbias && idx < Cout) {
+        float b = 0.f;
+        for (int k = 0; k < splits; ++k) b += bslab[(size_t)k * Cout + idx];
+        dbias[idx] = accumulate ? dbias[idx] + b : b;
+    }
+}
+
+struct WPlan { int P, twl, tiles_x, tiles_y, ntiles, splits, halo_w, halo_h; size_t lds, ws; };
+
+WPlan wgrad_plan(int N, int H, int W, int Cin, int Cout, int stride, int dtype) {
+    WPlan p;
+    const bool bf = dtype == WU_BF16;
+    p.P = bf ? (stride == 1 ? 256 : 128) : (stride == 1 ? 128 : 64);
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    int twl = 5;
+    while (twl > 2 && (1 << (twl - 1)) >= Wo) --twl;
+    p.twl = twl;
+    const int TW = 1 << twl, TH = p.P >> twl;
+    p.tiles_x = cdiv(Wo, TW); p.tiles_y = cdiv(Ho, TH);
+    p.ntiles = N * p.tiles_x * p.tiles_y;
+    const int blocks = (Cout / 64) * (Cin / 64);
+    int splits = cdiv(512, blocks);
+    if (splits > p.ntiles) splits = p.ntiles;
+    if (splits < 1) splits = 1;
+    p.splits = splits;
+    p.halo_w = (TW - 1) * stride + 3; p.halo_h = (TH - 1) * stride + 3;
+    const int rb = bf ? 128 : 256;
+    p.lds = (size_t)(p.P + p.halo_w * p.halo_h) * rb;
+    p.ws = ((size_t)splits * 9 * Cout * Cin + (size_t)splits * Cout) * sizeof(float);
+    return p;
+}
+
+template <typename T, int STRIDE, int P>
+void launch_wgrad(const WgradArgs& a, size_t lds, int grid, hipStream_t s) {
+    auto kern = conv3x3_wgrad_kernel<T, STRIDE, P>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+}
+
+}  // namespace
+
+extern "C" size_t wu_conv3x3_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int stride, int dtype) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin % 64 || Cout % 64 || (stride != 1 && stride != 2)) return 0;
+    return wgrad_plan(N, H, W, Cin, Cout, stride, dtype).ws;
+}
+
+extern "C" int wu_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy_, int act,
+                                float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes,
+                                int N, int H, int W, int Cin, int Cout, int stride, int accumulate,
+                                int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    WU_REQUIRE(dtype == WU_F32 || dtype == WU_BF16, "conv3x3_wgrad: bad dtype");
+    WU_REQUIRE(stride == 1 || stride == 2, "conv3x3_wgrad: stride");
+    WU_REQUIRE(N > 0 && H > 0 && W > 0 && Cin % 64 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0, "conv3x3_wgrad: Cin=%d Cout=%d must be multiples of 64", Cin, Cout);
+    WU_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && (ldx * esz) % 16 == 0 && (lddy * esz) % 16 == 0 && ldx >= Cin && lddy >= Cout, "conv3x3_wgrad: alignment");
+    if (y) WU_REQUIRE(((uintptr_t)y % 16) == 0 && (ldy_ * esz) % 16 == 0 && ldy_ >= Cout, "conv3x3_wgrad: y alignment");
+    const WPlan p = wgrad_plan(N, H, W, Cin, Cout, stride, dtype);
+    WU_REQUIRE(workspace && workspace_bytes >= p.ws && ((uintptr_t)workspace % 16) == 0, "conv3x3_wgrad: workspace too small (%zu < %zu)", workspace_bytes, p.ws);
+    WU_REQUIRE(p.lds <= 160 * 1024, "conv3x3_wgrad: LDS %zu", p.lds);
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.y = y;
+    a.slab = (float*)workspace;
+    a.bslab = dbias ? a.slab + (size_t)p.splits * 9 * Cout * Cin : nullptr;
+    a.ldx = ldx; a.lddy = lddy; a.ldy = ldy_;
+    a.N = N; a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cin = Cin; a.Cout = Cout;
+    a.act = act;
+    a.tw_log2 = p.twl; a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles;
+    a.splits = p.splits; a.co_blocks = Cout / 64; a.ci_blocks = Cin / 64;
+    a.halo_w = p.halo_w; a.halo_h = p.halo_h; a.halo_pix = p.halo_w * p.halo_h;
+    const int grid = p.splits * a.co_blocks * a.ci_blocks;
+    hipStream_t s = (hipStream_t)stream;
+    wu_prof_pre(WU_FAM_WGRAD, s);
+    if (dtype == WU_BF16) {
+        if (stride == 1) launch_wgrad<bf16_t, 1, 256>(a, p.lds, grid, s); else launch_wgrad<bf16_t, 2, 128>(a, p.lds, grid, s);
+    } else {
+        if (stride == 1) launch_wgrad<float, 1, 128>(a, p.lds, grid, s); else launch_wgrad<float, 2, 64>(a, p.lds, grid, s);
+    }
+    wu_prof_post(WU_FAM_WGRAD, s, 2.0 * N * a.Ho * a.Wo * 9.0 * Cin * Cout,
+                 ((double)N * H * W * Cin + (double)N * a.Ho * a.Wo * Cout * (y ? 2 : 1)) * esz + 9.0 * Cin * Cout * 4);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(Cout * Cin, 256)), dim3(256), 0, s, a.slab, a.bslab, dw_oihw, dbias, p.splits, Cout, Cin, accumulate);
+    WU_LAUNCH_CHECK("conv3x3_wgrad");
+    return 0;
+}

@@ -1,0 +1,569 @@
+// HBM-bound glue of the cUNet hot path: weight repack, MaxPool2d(2), AdaIN statistics, the fused
+// AdaIN-apply + bilinear x2 + dropout + concat-slice write (and its backward), sum-pool, layout helpers.
+// Every kernel moves 16 B per lane (8 bf16 / 4 fp32 channels of one NHWC pixel) so wave accesses
+// are 1 KiB contiguous wherever the tensor is dense.
+#include "wu_common.h"
+
+namespace {
+
+// =================================================================================================
+// weight repack (nets.py:20,22,28-31 weights, OIHW fp32) -> [tap][Cout][Cin] and [tap'][Cin][Cout]
+// =================================================================================================
+template <typename T>
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
+                                    int Cout, int Cin, const float* __restrict__ inv_sigma) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cout * Cin) return;
+    const int co = idx / Cin, ci = idx - co * Cin;
+    const float s = inv_sigma ? *inv_sigma : 1.f;
+    const float* src = w + (size_t)idx * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float v = src[t] * s;
+        if (wf) ElemTraits<T>::store(wf + ((size_t)t * Cout + co) * Cin + ci, v);
+        if (wd) ElemTraits<T>::store(wd + ((size_t)(8 - t) * Cin + ci) * Cout + co, v);
+    }
+}
+
+// =================================================================================================
+// MaxPool2d(2)   (cunet.py:27)
+// =================================================================================================
+template <typename T>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                    int N, int H, int W, int C) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int cpp = C / E, Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)N * Ho * Wo * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpp);
+        long long p = i / cpp;
+        const int ow = (int)(p % Wo); p /= Wo;
+        const int oh = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const T* src = x + ((size_t)(n * H + 2 * oh) * W + 2 * ow) * ldx + ch * E;
+        float m[E], v[E];
+        unpack16<T>(*(const uint4*)src, m);
+        unpack16<T>(*(const uint4*)(src + ldx), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) m[e] = (v[e] > m[e] || v[e] != v[e]) ? v[e] : m[e];
+        unpack16<T>(*(const uint4*)(src + (size_t)W * ldx), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) m[e] = (v[e] > m[e] || v[e] != v[e]) ? v[e] : m[e];
+        unpack16<T>(*(const uint4*)(src + (size_t)W * ldx + ldx), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) m[e] = (v[e] > m[e] || v[e] != v[e]) ? v[e] : m[e];
+        *(uint4*)(y + ((size_t)(n * Ho + oh) * Wo + ow) * ldy + ch * E) = pack16<T>(m);
+    }
+}
+
+// dx = dskip + route(dy): the window's first maximum (scan order (0,0),(0,1),(1,0),(1,1), strict >,
+// PyTorch's rule) receives dy.
+template <typename T>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                    const T* __restrict__ dskip, int lddskip, T* __restrict__ dx, int lddx,
+                                    int N, int H, int W, int C) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int cpp = C / E, Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)N * Ho * Wo * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpp);
+        long long p = i / cpp;
+        const int ow = (int)(p % Wo); p /= Wo;
+        const int oh = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const size_t pix = (size_t)(n * H + 2 * oh) * W + 2 * ow;
+        float v[4][E], g[E];
+        const size_t offs[4] = {0, 1, (size_t)W, (size_t)W + 1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) unpack16<T>(*(const uint4*)(x + (pix + offs[k]) * ldx + ch * E), v[k]);
+        unpack16<T>(*(const uint4*)(dy + ((size_t)(n * Ho + oh) * Wo + ow) * lddy + ch * E), g);
+        int arg[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            float m = v[0][e];
+            arg[e] = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (v[k][e] > m || v[k][e] != v[k][e]) { m = v[k][e]; arg[e] = k; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float o[E];
+            if (dskip) unpack16<T>(*(const uint4*)(dskip + (pix + offs[k]) * lddskip + ch * E), o);
+#pragma unroll
+            for (int e = 0; e < E; ++e) o[e] = (dskip ? o[e] : 0.f) + (arg[e] == k ? g[e] : 0.f);
+            *(uint4*)(dx + (pix + offs[k]) * lddx + ch * E) = pack16<T>(o);
+        }
+    }
+}
+
+// =================================================================================================
+// AdaIN statistics (utils.py:34-39): shifted sums per (n,c), finalised to {mean, rstd}
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void adain_stats_kernel(const T* __restrict__ x, int ldx, float* __restrict__ scratch,
+                                                          int HW, int C, int splits) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    constexpr int LP = 64 / E;         // lanes per pixel (64 channels per workgroup)
+    constexpr int PP = 256 / LP;       // pixels per iteration
+    __shared__ float red[64][2];
+    const int tid = threadIdx.x;
+    const int cg = blockIdx.x, split = blockIdx.y, n = blockIdx.z;
+    if (tid < 128) red[tid >> 1][tid & 1] = 0.f;
+    __syncthreads();
+    const int cl = tid % LP, pl = tid / LP;
+    const T* base = x + (size_t)n * HW * ldx + cg * 64 + cl * E;
+    float k[E], s1[E], s2[E], v[E];
+    unpack16<T>(*(const uint4*)base, k);   // shift = the value at pixel 0 (kills the cancellation)
+#pragma unroll
+    for (int e = 0; e < E; ++e) s1[e] = s2[e] = 0.f;
+    const int per = (HW + splits - 1) / splits;
+    const int p0 = split * per, p1 = min(HW, p0 + per);
+    for (int p = p0 + pl; p < p1; p += PP) {
+        unpack16<T>(*(const uint4*)(base + (size_t)p * ldx), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float d = v[e] - k[e];
+            s1[e] += d;
+            s2[e] += d * d;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        atomicAdd(&red[cl * E + e][0], s1[e]);
+        atomicAdd(&red[cl * E + e][1], s2[e]);
+    }
+    __syncthreads();
+    if (tid < 128) atomicAdd(&scratch[((size_t)n * C + cg * 64 + (tid >> 1)) * 2 + (tid & 1)], red[tid >> 1][tid & 1]);
+}
+
+template <typename T>
+__global__ void adain_stats_final_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scratch,
+                                         float* __restrict__ stats, int N, int HW, int C, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    const float k = ElemTraits<T>::load(x + (size_t)n * HW * ldx + c);
+    const float s1 = scratch[2 * i], s2 = scratch[2 * i + 1];
+    const float cnt = (float)HW;
+    const float mean = k + s1 / cnt;
+    const float var = fmaxf((s2 - s1 * s1 / cnt) / (cnt - 1.f), 0.f);   // unbiased (torch.var default), utils.py:36
+    stats[2 * i] = mean;
+    stats[2 * i + 1] = 1.f / sqrtf(var + eps);
+}
+
+// =================================================================================================
+// fused AdaIN apply + bilinear x2 (align_corners) + dropout -> concat slice   (cunet.py:59-62)
+// =================================================================================================
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp src_index(int dst, float scale, int in_size) {
+    // PyTorch area_pixel_compute_source_index(align_corners=True): src = scale * dst, in fp32
+    const float src = scale * (float)dst;
+    Lerp r;
+    r.i0 = (int)src;
+    r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
+    r.l1 = src - (float)r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+
+// keep-mask bits for the 8 (or 4) channels starting at NHWC linear index idx (idx % 4 == 0)
+template <int E> __device__ __forceinline__ void keep_bits(uint64_t seed, uint64_t idx, uint32_t thr, bool* keep) {
+#pragma unroll
+    for (int q = 0; q < E / 4; ++q) {
+        const uint64_t r = wu_rand4(seed, (idx >> 2) + q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep[4 * q + e] = (uint32_t)((r >> (16 * e)) & 0xffff) < thr;
+    }
+}
+
+template <typename T>
+__global__ void adain_upcat_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ stats,
+                                       const float* __restrict__ y_std, const float* __restrict__ y_mean,
+                                       T* __restrict__ y, int ldy, int N, int H, int W, int C,
+                                       float sy, float sx, uint32_t thr, float keep_scale, uint64_t seed) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int cpp = C / E, H2 = 2 * H, W2 = 2 * W;
+    const long long total = (long long)N * H2 * W2 * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpp);
+        long long p = i / cpp;
+        const int ow = (int)(p % W2); p /= W2;
+        const int oh = (int)(p % H2);
+        const int n = (int)(p / H2);
+        const Lerp ly = src_index(oh, sy, H), lx = src_index(ow, sx, W);
+        const T* b = x + (size_t)n * H * W * ldx + ch * E;
+        float v00[E], v01[E], v10[E], v11[E], o[E];
+        unpack16<T>(*(const uint4*)(b + (size_t)(ly.i0 * W + lx.i0) * ldx), v00);
+        unpack16<T>(*(const uint4*)(b + (size_t)(ly.i0 * W + lx.i1) * ldx), v01);
+        unpack16<T>(*(const uint4*)(b + (size_t)(ly.i1 * W + lx.i0) * ldx), v10);
+        unpack16<T>(*(const uint4*)(b + (size_t)(ly.i1 * W + lx.i1) * ldx), v11);
+        bool keep[E];
+        if (thr < 0x10000u) keep_bits<E>(seed, (uint64_t)((size_t)(n * H2 + oh) * W2 + ow) * C + ch * E, thr, keep);
+        const int sc = n * C + ch * E;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float v = ly.l0 * (lx.l0 * v00[e] + lx.l1 * v01[e]) + ly.l1 * (lx.l0 * v10[e] + lx.l1 * v11[e]);
+            const float mean = stats[2 * (sc + e)], rstd = stats[2 * (sc + e) + 1];
+            float r = (v - mean) * (rstd * y_std[sc + e]) + y_mean[sc + e];   // utils.py:49-50
+            if (thr < 0x10000u) r = keep[e] ? r * keep_scale : 0.f;           // nn.Dropout(p) train mode
+            o[e] = r;
+        }
+        *(uint4*)(y + ((size_t)(n * H2 + oh) * W2 + ow) * ldy + ch * E) = pack16<T>(o);
+    }
+}
+
+// backward stage A: g'[n,y,x,c] = sum over the output pixels that interpolate from (y,x) of
+// weight * dropout * dy  (the gradient wrt the AdaIN output), plus per-(n,c) sums of g' and g'*xhat.
+template <typename T>
+__global__ __launch_bounds__(256) void adain_upcat_bwd_gather_kernel(
+    const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx, const float* __restrict__ stats,
+    float* __restrict__ gtmp, float* __restrict__ sums, int H, int W, int C,
+    float sy, float sx, uint32_t thr, float keep_scale, uint64_t seed) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    constexpr int LP = 64 / E, PP = 256 / LP;
+    __shared__ float red[64][2];
+    const int tid = threadIdx.x;
+    const int cg = blockIdx.x, n = blockIdx.z;
+    if (tid < 128) red[tid >> 1][tid & 1] = 0.f;
+    __syncthreads();
+    const int cl = tid % LP, pl = tid / LP;
+    const int c0 = cg * 64 + cl * E;
+    const int H2 = 2 * H, W2 = 2 * W, HW = H * W;
+    float s1[E], s2[E], mean[E], rstd[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        s1[e] = s2[e] = 0.f;
+        mean[e] = stats[2 * (n * C + c0 + e)];
+        rstd[e] = stats[2 * (n * C + c0 + e) + 1];
+    }
+    const int per = (HW + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * per, p1 = min(HW, p0 + per);
+    for (int p = p0 + pl; p < p1; p += PP) {
+        const int yy = p / W, xx = p - yy * W;
+        float g[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) g[e] = 0.f;
+        for (int i = max(0, 2 * yy - 2); i <= min(H2 - 1, 2 * yy + 3); ++i) {
+            const Lerp ly = src_index(i, sy, H);
+            const float wy = (ly.i0 == yy ? ly.l0 : 0.f) + (ly.i1 == yy ? ly.l1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int j = max(0, 2 * xx - 2); j <= min(W2 - 1, 2 * xx + 3); ++j) {
+                const Lerp lx = src_index(j, sx, W);
+                const float wx = (lx.i0 == xx ? lx.l0 : 0.f) + (lx.i1 == xx ? lx.l1 : 0.f);
+                if (wx == 0.f) continue;
+                const size_t opix = (size_t)(n * H2 + i) * W2 + j;
+                float d[E];
+                unpack16<T>(*(const uint4*)(dy + opix * lddy + c0), d);
+                float wgt = wy * wx;
+                if (thr < 0x10000u) {
+                    bool keep[E];
+                    keep_bits<E>(seed, (uint64_t)opix * C + c0, thr, keep);
+                    wgt *= keep_scale;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) g[e] += keep[e] ? wgt * d[e] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) g[e] += wgt * d[e];
+                }
+            }
+        }
+        float xv[E];
+        unpack16<T>(*(const uint4*)(x + ((size_t)n * HW + p) * ldx + c0), xv);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            s1[e] += g[e];
+            s2[e] += g[e] * ((xv[e] - mean[e]) * rstd[e]);
+        }
+        float* gd = gtmp + ((size_t)n * HW + p) * C + c0;
+#pragma unroll
+        for (int e = 0; e < E; e += 4) *(float4*)(gd + e) = make_float4(g[e], g[e + 1], g[e + 2], g[e + 3]);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        atomicAdd(&red[cl * E + e][0], s1[e]);
+        atomicAdd(&red[cl * E + e][1], s2[e]);
+    }
+    __syncthreads();
+    if (tid < 128) atomicAdd(&sums[((size_t)n * C + cg * 64 + (tid >> 1)) * 2 + (tid & 1)], red[tid >> 1][tid & 1]);
+}
+
+// backward stage B: dx = y_std*rstd * (g' - mean(g') - xhat * sum(g'*xhat)/(HW-1));  d_y_mean = sum g',
+// d_y_std = sum g'*xhat.
+template <typename T>
+__global__ void adain_upcat_bwd_apply_kernel(const float* __restrict__ gtmp, const float* __restrict__ sums,
+                                             const T* __restrict__ x, int ldx, const float* __restrict__ stats,
+                                             const float* __restrict__ y_std, T* __restrict__ dx, int lddx,
+                                             float* __restrict__ d_y_std, float* __restrict__ d_y_mean,
+                                             int N, int HW, int C) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int cpp = C / E;
+    const long long total = (long long)N * HW * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpp);
+        const long long p = i / cpp;            // n*HW + pixel
+        const int n = (int)(p / HW);
+        const int sc = n * C + ch * E;
+        float xv[E], o[E];
+        unpack16<T>(*(const uint4*)(x + (size_t)p * ldx + ch * E), xv);
+        const float* g = gtmp + (size_t)p * C + ch * E;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float mean = stats[2 * (sc + e)], rstd = stats[2 * (sc + e) + 1];
+            const float S1 = sums[2 * (sc + e)], S2 = sums[2 * (sc + e) + 1];
+            const float xh = (xv[e] - mean) * rstd;
+            o[e] = y_std[sc + e] * rstd * (g[e] - S1 / (float)HW - xh * S2 / (float)(HW - 1));
+            if (p % HW == 0) {
+                d_y_mean[sc + e] = S1;
+                d_y_std[sc + e] = S2;
+            }
+        }
+        *(uint4*)(dx + (size_t)p * lddx + ch * E) = pack16<T>(o);
+    }
+}
+
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ mask, int N, int H2, int W2, int C, uint32_t thr, uint64_t seed) {
+    const long long total = (long long)N * H2 * W2 * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // i = NHWC linear index (the RNG's index space); write NCHW
+        const int c = (int)(i % C);
+        long long p = i / C;
+        const int w = (int)(p % W2); p /= W2;
+        const int h = (int)(p % H2);
+        const int n = (int)(p / H2);
+        const uint64_t r = wu_rand4(seed, (uint64_t)i >> 2);
+        const bool keep = (uint32_t)((r >> (16 * (i & 3))) & 0xffff) < thr;
+        mask[((size_t)(n * C + c) * H2 + h) * W2 + w] = keep ? 1 : 0;
+    }
+}
+
+// =================================================================================================
+// sum-pool (disc.py:32) and layout helpers
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void sumpool_fwd_kernel(const T* __restrict__ x, int ldx, float* __restrict__ feat, int HW, int C) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    constexpr int LP = 64 / E, PP = 256 / LP;
+    __shared__ float red[64];
+    const int tid = threadIdx.x, cg = blockIdx.x, n = blockIdx.y;
+    if (tid < 64) red[tid] = 0.f;
+    __syncthreads();
+    const int cl = tid % LP, pl = tid / LP;
+    const T* base = x + (size_t)n * HW * ldx + cg * 64 + cl * E;
+    float s[E], v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[e] = 0.f;
+    for (int p = pl; p < HW; p += PP) {
+        unpack16<T>(*(const uint4*)(base + (size_t)p * ldx), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) atomicAdd(&red[cl * E + e], s[e]);
+    __syncthreads();
+    if (tid < 64) feat[(size_t)n * C + cg * 64 + tid] = red[tid];
+}
+
+template <typename T>
+__global__ void sumpool_bwd_kernel(const float* __restrict__ dfeat, T* __restrict__ dx, int lddx, int N, int HW, int C) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int cpp = C / E;
+    const long long total = (long long)N * HW * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpp);
+        const long long p = i / cpp;
+        const int n = (int)(p / HW);
+        float o[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = dfeat[(size_t)n * C + ch * E + e];
+        *(uint4*)(dx + (size_t)p * lddx + ch * E) = pack16<T>(o);
+    }
+}
+
+// NHWC T -> NCHW fp32 through a 32x32 LDS tile (pixels x channels)
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, int ldx, float* __restrict__ y, int HW, int C) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        tile[r][tx] = (p < HW && c < C) ? ElemTraits<T>::load(x + ((size_t)n * HW + p) * ldx + c) : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (p < HW && c < C) y[((size_t)n * C + c) * HW + p] = tile[tx][r];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int ldy, int HW, int C) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        tile[r][tx] = (p < HW && c < C) ? x[((size_t)n * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        if (p < HW && c < C) ElemTraits<T>::store(y + ((size_t)n * HW + p) * ldy + c, tile[tx][r]);
+    }
+}
+
+inline int grid_for(long long total, int block = 256, int cap = 256 * 16) {
+    long long g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+inline bool ok16(const void* p, int ld, int esz) { return ((uintptr_t)p % 16) == 0 && (ld * esz) % 16 == 0; }
+inline uint32_t keep_thr(float p) {
+    if (p <= 0.f) return 0x10000u;
+    return (uint32_t)((1.0 - (double)p) * 65536.0 + 0.5);
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                         \
+    do {                                               \
+        if ((dtype) == WU_BF16) { using T = bf16_t; __VA_ARGS__; } \
+        else { using T = float; __VA_ARGS__; }         \
+    } while (0)
+
+extern "C" int wu_pack_conv3x3(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin,
+                               const float* inv_sigma, int dtype, void* stream) {
+    WU_REQUIRE(dtype == WU_F32 || dtype == WU_BF16, "pack_conv3x3: bad dtype");
+    WU_REQUIRE(Cout > 0 && Cin > 0 && w_oihw, "pack_conv3x3: bad shape");
+    const int total = Cout * Cin;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv3x3_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                                         w_oihw, (T*)w_fwd, (T*)w_dgrad, Cout, Cin, inv_sigma));
+    WU_LAUNCH_CHECK("pack_conv3x3");
+    return 0;
+}
+
+extern "C" int wu_maxpool2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    WU_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % (16 / esz) == 0 && C <= ldx && C <= ldy, "maxpool2_fwd: bad shape H=%d W=%d C=%d", H, W, C);
+    WU_REQUIRE(ok16(x, ldx, esz) && ok16(y, ldy, esz), "maxpool2_fwd: alignment");
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / (16 / esz));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)x, ldx, (T*)y, ldy, N, H, W, C));
+    WU_LAUNCH_CHECK("maxpool2_fwd");
+    return 0;
+}
+
+extern "C" int wu_maxpool2_bwd(const void* x, int ldx, const void* dy, int lddy, const void* dskip, int lddskip,
+                               void* dx, int lddx, int N, int H, int W, int C, int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    WU_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % (16 / esz) == 0, "maxpool2_bwd: bad shape");
+    WU_REQUIRE(ok16(x, ldx, esz) && ok16(dy, lddy, esz) && ok16(dx, lddx, esz) && (!dskip || ok16(dskip, lddskip, esz)), "maxpool2_bwd: alignment");
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / (16 / esz));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)x, ldx, (const T*)dy, lddy, (const T*)dskip, lddskip, (T*)dx, lddx, N, H, W, C));
+    WU_LAUNCH_CHECK("maxpool2_bwd");
+    return 0;
+}
+
+extern "C" int wu_adain_stats(const void* x, int ldx, float* stats, float* scratch, int N, int H, int W, int C,
+                              float eps, int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    WU_REQUIRE(C % 64 == 0 && H * W > 1 && ok16(x, ldx, esz), "adain_stats: bad shape C=%d HW=%d", C, H * W);
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = H * W;
+    int splits = cdiv(1024, N * (C / 64));
+    if (splits > cdiv(HW, 256)) splits = cdiv(HW, 256);
+    if (splits < 1) splits = 1;
+    hipError_t e = hipMemsetAsync(scratch, 0, (size_t)N * C * 2 * sizeof(float), s);
+    if (e != hipSuccess) WU_FAIL((int)e, "adain_stats: memset: %s", hipGetErrorString(e));
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL(adain_stats_kernel<T>, dim3(C / 64, splits, N), dim3(256), 0, s, (const T*)x, ldx, scratch, HW, C, splits);
+        hipLaunchKernelGGL(adain_stats_final_kernel<T>, dim3(cdiv(N * C, 256)), dim3(256), 0, s, (const T*)x, ldx, scratch, stats, N, HW, C, eps);
+    });
+    WU_LAUNCH_CHECK("adain_stats");
+    return 0;
+}
+
+extern "C" int wu_adain_upcat_fwd(const void* x, int ldx, const float* stats, const float* y_std, const float* y_mean,
+                                  void* y, int ldy, int N, int H, int W, int C, float p_drop, uint64_t seed,
+                                  int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    WU_REQUIRE(C % (16 / esz) == 0 && C <= ldx && C <= ldy && H > 1 && W > 1, "adain_upcat_fwd: bad shape");
+    WU_REQUIRE(ok16(x, ldx, esz) && ok16(y, ldy, esz), "adain_upcat_fwd: alignment");
+    WU_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "adain_upcat_fwd: p_drop");
+    const float sy = (float)(H - 1) / (float)(2 * H - 1), sx = (float)(W - 1) / (float)(2 * W - 1);
+    const long long total = (long long)N * 4 * H * W * (C / (16 / esz));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(adain_upcat_fwd_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)x, ldx, stats, y_std, y_mean, (T*)y, ldy, N, H, W, C, sy, sx,
+                                         keep_thr(p_drop), 1.f / (1.f - p_drop), seed));
+    WU_LAUNCH_CHECK("adain_upcat_fwd");
+    return 0;
+}
+
+extern "C" int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int ldx, const float* stats, const float* y_std,
+                                  void* dx, int lddx, float* d_y_std, float* d_y_mean, float* gtmp, float* sums,
+                                  int N, int H, int W, int C, float p_drop, uint64_t seed, int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    WU_REQUIRE(C % 64 == 0 && H > 1 && W > 1, "adain_upcat_bwd: bad shape");
+    WU_REQUIRE(ok16(x, ldx, esz) && ok16(dy, lddy, esz) && ok16(dx, lddx, esz) && ((uintptr_t)gtmp % 16) == 0, "adain_upcat_bwd: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    const float sy = (float)(H - 1) / (float)(2 * H - 1), sx = (float)(W - 1) / (float)(2 * W - 1);
+    const int HW = H * W;
+    int splits = cdiv(2048, N * (C / 64));
+    const int pp = 256 / (64 / (16 / esz));
+    if (splits > cdiv(HW, pp)) splits = cdiv(HW, pp);
+    if (splits < 1) splits = 1;
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)N * C * 2 * sizeof(float), s);
+    if (e != hipSuccess) WU_FAIL((int)e, "adain_upcat_bwd: memset: %s", hipGetErrorString(e));
+    const long long total = (long long)N * HW * (C / (16 / esz));
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL(adain_upcat_bwd_gather_kernel<T>, dim3(C / 64, splits, N), dim3(256), 0, s, (const T*)dy, lddy, (const T*)x, ldx,
+                           stats, gtmp, sums, H, W, C, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), seed);
+        hipLaunchKernelGGL(adain_upcat_bwd_apply_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, gtmp, sums, (const T*)x, ldx, stats, y_std,
+                           (T*)dx, lddx, d_y_std, d_y_mean, N, HW, C);
+    });
+    WU_LAUNCH_CHECK("adain_upcat_bwd");
+    return 0;
+}
+
+extern "C" int wu_dropout_mask(uint8_t* mask_nchw, int N, int H2, int W2, int C, float p_drop, uint64_t seed, void* stream) {
+    WU_REQUIRE(C % 4 == 0, "dropout_mask: C %% 4");
+    const long long total = (long long)N * H2 * W2 * C;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, mask_nchw, N, H2, W2, C, keep_thr(p_drop), seed);
+    WU_LAUNCH_CHECK("dropout_mask");
+    return 0;
+}
+
+extern "C" int wu_sumpool_fwd(const void* x, int ldx, float* feat, int N, int H, int W, int C, int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    WU_REQUIRE(C % 64 == 0 && ok16(x, ldx, esz), "sumpool_fwd: bad shape");
+    DISPATCH_T(dtype, hipLaunchKernelGGL(sumpool_fwd_kernel<T>, dim3(C / 64, N), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, feat, H * W, C));
+    WU_LAUNCH_CHECK("sumpool_fwd");
+    return 0;
+}
+
+extern "C" int wu_sumpool_bwd(const float* dfeat, void* dx, int lddx, int N, int H, int W, int C, int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    WU_REQUIRE(C % (16 / esz) == 0 && ok16(dx, lddx, esz), "sumpool_bwd: bad shape");
+    const long long total = (long long)N * H * W * (C / (16 / esz));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(sumpool_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dfeat, (T*)dx, lddx, N, H * W, C));
+    WU_LAUNCH_CHECK("sumpool_bwd");
+    return 0;
+}
+
+extern "C" int wu_nhwc_to_nchw_f32(const void* x, int ldx, float* y_nchw, int N, int H, int W, int C, int dtype, void* stream) {
+    WU_REQUIRE(N > 0 && H * W > 0 && C > 0, "nhwc_to_nchw: bad shape");
+    DISPATCH_T(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(cdiv(H * W, 32), cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)x, ldx, y_nchw, H * W, C));
+    WU_LAUNCH_CHECK("nhwc_to_nchw");
+    return 0;
+}
+
+extern "C" int wu_nchw_f32_to_nhwc(const float* x_nchw, void* y, int ldy, int N, int H, int W, int C, int dtype, void* stream) {
+    WU_REQUIRE(N > 0 && H * W > 0 && C > 0, "nchw_to_nhwc: bad shape");
+    DISPATCH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(cdiv(H * W, 32), cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream,
+                                         x_nchw, (T*)y, ldy, H * W, C));
+    WU_LAUNCH_CHECK("nchw_to_nhwc");
+    return 0;
+}

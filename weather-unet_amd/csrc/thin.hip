@@ -1,0 +1,372 @@
+// Thin, HBM-bound ends of the networks (no MFMA: K = 27 or N = 3 cannot feed a matrix core):
+//   - 3-input-channel conv3x3 read straight from the NCHW fp32 image: dconv_down1[0] (cunet.py:45 via
+//     nets.py:20), disc.conv1[0] (3->3, s1) and disc.conv1[1] (3->64, s2) (disc.py:28 via nets.py:28-31);
+//   - conv_last 1x1 (64->3) + tanh (cunet.py:39-40,80-82), forward and backward.
+#include "wu_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// conv3x3, Cin = 3, NCHW fp32 input.  One thread = one output pixel x all COUT channels; the 27 x COUT
+// weights sit in LDS and are read as wave-uniform (broadcast) float4s.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int COUT, int STRIDE, bool OUT_NCHW>
+__global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const float* __restrict__ inv_sigma,
+                                                             void* __restrict__ yv, int ldy, int N, int H, int W, int act) {
+    constexpr int CP = (COUT + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) float wl[27][CP];
+    __shared__ float bl[CP];
+    const float s = inv_sigma ? *inv_sigma : 1.f;
+    for (int i = threadIdx.x; i < 27 * CP; i += 256) {
+        const int k = i / CP, co = i - k * CP;          // k = ci*9 + tap  (OIHW: w[co][ci][kh][kw])
+        wl[k][co] = co < COUT ? w[co * 27 + k] * s : 0.f;
+    }
+    if (threadIdx.x < CP) bl[threadIdx.x] = (bias && threadIdx.x < COUT) ? bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
+    const long long total = (long long)N * Ho * Wo;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ow = (int)(i % Wo);
+        const int oh = (int)((i / Wo) % Ho);
+        const int n = (int)(i / ((long long)Wo * Ho));
+        float acc[CP];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) acc[c] = bl[c];
+        const float* xn = x + (size_t)n * 3 * H * W;
+#pragma unroll 1
+        for (int k = 0; k < 27; ++k) {
+            const int ci = k / 9, t = k - ci * 9, kh = t / 3, kw = t - kh * 3;
+            const int ih = oh * STRIDE + kh - 1, iw = ow * STRIDE + kw - 1;
+            const float v = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? xn[((size_t)ci * H + ih) * W + iw] : 0.f;
+            const float4* wr = (const float4*)wl[k];
+#pragma unroll
+            for (int c4 = 0; c4 < CP / 4; ++c4) {
+                const float4 ww = wr[c4];
+                acc[4 * c4 + 0] += v * ww.x; acc[4 * c4 + 1] += v * ww.y;
+                acc[4 * c4 + 2] += v * ww.z; acc[4 * c4 + 3] += v * ww.w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = act_apply(acc[c], act);
+        if (OUT_NCHW) {
+            float* y = (float*)yv;
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) y[((size_t)(n * COUT + c) * Ho + oh) * Wo + ow] = acc[c];
+        } else {
+            constexpr int E = ElemTraits<T>::kPer16B;
+            T* y = (T*)yv + (size_t)i * ldy;
+#pragma unroll
+            for (int c = 0; c + E <= COUT; c += E) *(uint4*)(y + c) = pack16<T>(acc + c);
+        }
+    }
+}
+
+// weight/bias gradient: dW[co][k] += sum_pix dy'[pix][co] * patch[pix][k], k = ci*9+tap (27).
+// Workgroup = 64 couts x 4 k-groups; pixels staged through LDS in batches of 64.
+template <typename T, int STRIDE, bool DY_NCHW>
+__global__ __launch_bounds__(256) void conv3x3_c3_wgrad_kernel(const float* __restrict__ x, const void* __restrict__ dyv, int lddy,
+                                                               const void* __restrict__ yv, int ldy, int act,
+                                                               float* __restrict__ dw, float* __restrict__ dbias,
+                                                               int N, int H, int W, int Cout) {
+    __shared__ float patch[27][64];
+    __shared__ float dyl[64][65];
+    const int tid = threadIdx.x, co = tid & 63, q = tid >> 6;
+    const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
+    const long long total = (long long)N * Ho * Wo;
+    const int cog = blockIdx.y * 64;     // cout group
+    float acc[7], bsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[j] = 0.f;
+    for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
+        for (int i = tid; i < 27 * 64; i += 256) {
+            const int k = i >> 6, p = i & 63;
+            const long long pix = base + p;
+            float v = 0.f;
+            if (pix < total) {
+                const int ow = (int)(pix % Wo), oh = (int)((pix / Wo) % Ho), n = (int)(pix / ((long long)Wo * Ho));
+                const int ci = k / 9, t = k - ci * 9, ih = oh * STRIDE + t / 3 - 1, iw = ow * STRIDE + t % 3 - 1;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = x[(((size_t)n * 3 + ci) * H + ih) * W + iw];
+            }
+            patch[k][p] = v;
+        }
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int p = i >> 6, c = i & 63;
+            const long long pix = base + p;
+            float g = 0.f;
+            if (pix < total && cog + c < Cout) {
+                if (DY_NCHW) {
+                    const int hw = Ho * Wo;
+                    const size_t o = ((size_t)(pix / hw) * Cout + cog + c) * hw + (pix % hw);
+                    g = ((const float*)dyv)[o];
+                    if (yv) g = act_gate(g, ((const float*)yv)[o], act);
+                } else {
+                    g = ElemTraits<T>::load((const T*)dyv + (size_t)pix * lddy + cog + c);
+                    if (yv) g = act_gate(g, ElemTraits<T>::load((const T*)yv + (size_t)pix * ldy + cog + c), act);
+                }
+            }
+            dyl[p][c] = g;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int p = 0; p < 64; ++p) {
+            const float d = dyl[p][co];
+            if (q == 0) bsum += d;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int k = q + 4 * j;
+                if (k < 27) acc[j] += d * patch[k][p];
+            }
+        }
+        __syncthreads();
+    }
+    if (cog + co < Cout) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int k = q + 4 * j;
+            if (k < 27) atomicAdd(&dw[(size_t)(cog + co) * 27 + k], acc[j]);
+        }
+        if (q == 0 && dbias) atomicAdd(&dbias[cog + co], bsum);
+    }
+}
+
+// data gradient wrt the NCHW fp32 image (D differentiated wrt G's output): one thread = one input pixel.
+template <typename T, int STRIDE, bool DY_NCHW>
+__global__ __launch_bounds__(256) void conv3x3_c3_dgrad_kernel(const void* __restrict__ dyv, int lddy, const void* __restrict__ yv, int ldy,
+                                                               int act, const float* __restrict__ w, const float* __restrict__ inv_sigma,
+                                                               float* __restrict__ dx, int N, int H, int W, int Cout, int accumulate) {
+    extern __shared__ float wl[];   // [27][Cout]
+    const float s = inv_sigma ? *inv_sigma : 1.f;
+    for (int i = threadIdx.x; i < 27 * Cout; i += 256) {
+        const int k = i / Cout, co = i - k * Cout;
+        wl[i] = w[co * 27 + k] * s;
+    }
+    __syncthreads();
+    const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
+    const long long total = (long long)N * H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int iw = (int)(i % W), ih = (int)((i / W) % H), n = (int)(i / ((long long)W * H));
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int th = ih + 1 - kh;
+            if (th < 0 || th % STRIDE) continue;
+            const int oh = th / STRIDE;
+            if (oh >= Ho) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tw = iw + 1 - kw;
+                if (tw < 0 || tw % STRIDE) continue;
+                const int ow = tw / STRIDE;
+                if (ow >= Wo) continue;
+                const int t = kh * 3 + kw;
+                const size_t pix = ((size_t)n * Ho + oh) * Wo + ow;
+                for (int co = 0; co < Cout; ++co) {
+                    float g;
+                    if (DY_NCHW) {
+                        const size_t o = (((size_t)n * Cout + co) * Ho + oh) * Wo + ow;
+                        g = ((const float*)dyv)[o];
+                        if (yv) g = act_gate(g, ((const float*)yv)[o], act);
+                    } else {
+                        g = ElemTraits<T>::load((const T*)dyv + pix * lddy + co);
+                        if (yv) g = act_gate(g, ElemTraits<T>::load((const T*)yv + pix * ldy + co), act);
+                    }
+                    a0 += g * wl[(0 * 9 + t) * Cout + co];
+                    a1 += g * wl[(1 * 9 + t) * Cout + co];
+                    a2 += g * wl[(2 * 9 + t) * Cout + co];
+                }
+            }
+        }
+        const size_t hw = (size_t)H * W, o = (size_t)n * 3 * hw + (size_t)ih * W + iw;
+        if (accumulate) { dx[o] += a0; dx[o + hw] += a1; dx[o + 2 * hw] += a2; }
+        else { dx[o] = a0; dx[o + hw] = a1; dx[o + 2 * hw] = a2; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv_last (1x1, Cin -> 3) + tanh.  LP lanes share one pixel (16 B of channels each): a wave load is
+// 64/LP full pixel rows; the three dot products are finished with xor-shuffles.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_tanh_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               int N, int HW, int Cin) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int LP = Cin / E;                      // lanes per pixel (8 for bf16/64ch, 16 for fp32/64ch)
+    const int tid = threadIdx.x, cl = tid % LP;
+    float wr[3][E];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < E; ++e) wr[k][e] = w[k * Cin + cl * E + e];
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
+    const int ppi = 256 / LP;
+    const long long total = (long long)N * HW;
+    const long long iters = (total + ppi - 1) / ppi;
+    for (long long it = blockIdx.x; it < iters; it += gridDim.x) {
+        const long long pix = it * ppi + tid / LP;
+        float v[E], s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        if (pix < total) {
+            unpack16<T>(*(const uint4*)(x + (size_t)pix * ldx + cl * E), v);
+#pragma unroll
+            for (int e = 0; e < E; ++e) { s0 += v[e] * wr[0][e]; s1 += v[e] * wr[1][e]; s2 += v[e] * wr[2][e]; }
+        }
+        for (int m = LP >> 1; m > 0; m >>= 1) {
+            s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m);
+        }
+        if (cl == 0 && pix < total) {
+            const long long n = pix / HW, p = pix - n * HW;
+            float* o = out + (size_t)n * 3 * HW + p;
+            o[0] = tanhf(s0 + b0); o[HW] = tanhf(s1 + b1); o[2 * (size_t)HW] = tanhf(s2 + b2);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_tanh_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                               const T* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                               T* __restrict__ dx, int lddx, float* __restrict__ dw, float* __restrict__ dbias,
+                                                               int N, int HW, int Cin) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    __shared__ float red[3][65];      // [k][channel] + [k][64] = bias
+    const int LP = Cin / E;
+    const int tid = threadIdx.x, cl = tid % LP;
+    for (int i = tid; i < 3 * 65; i += 256) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+    float wr[3][E], aw[3][E], ab[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < E; ++e) { wr[k][e] = w[k * Cin + cl * E + e]; aw[k][e] = 0.f; }
+    const int ppi = 256 / LP;
+    const long long total = (long long)N * HW;
+    const long long iters = (total + ppi - 1) / ppi;
+    for (long long it = blockIdx.x; it < iters; it += gridDim.x) {
+        const long long pix = it * ppi + tid / LP;
+        if (pix >= total) continue;
+        const long long n = pix / HW, p = pix - n * HW;
+        const size_t o = (size_t)n * 3 * HW + p;
+        float g[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float t = out[o + (size_t)k * HW];
+            g[k] = dout[o + (size_t)k * HW] * (1.f - t * t);    // d tanh
+        }
+        float v[E], d[E];
+        unpack16<T>(*(const uint4*)(x + (size_t)pix * ldx + cl * E), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            d[e] = g[0] * wr[0][e] + g[1] * wr[1][e] + g[2] * wr[2][e];
+            aw[0][e] += g[0] * v[e]; aw[1][e] += g[1] * v[e]; aw[2][e] += g[2] * v[e];
+        }
+        if (cl == 0) { ab[0] += g[0]; ab[1] += g[1]; ab[2] += g[2]; }
+        *(uint4*)(dx + (size_t)pix * lddx + cl * E) = pack16<T>(d);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) atomicAdd(&red[k][cl * E + e], aw[k][e]);
+        if (cl == 0) atomicAdd(&red[k][64], ab[k]);
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * Cin; i += 256) atomicAdd(&dw[i], red[i / Cin][i % Cin]);
+    if (tid < 3) atomicAdd(&dbias[tid], red[tid][64]);
+}
+
+inline int grid_cap(long long work_items, int per_block, int cap) {
+    long long g = (work_items + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int wu_conv3x3_c3_fwd(const float* x_nchw, const float* w_oihw, const float* bias, const float* inv_sigma,
+                                 void* y, int ldy, int out_nchw, int N, int H, int W, int Cout, int stride, int act,
+                                 int dtype, void* stream) {
+    WU_REQUIRE(stride == 1 || stride == 2, "conv3x3_c3_fwd: stride");
+    WU_REQUIRE((Cout == 64 && !out_nchw) || (Cout == 3 && out_nchw && stride == 1), "conv3x3_c3_fwd: supported (Cout,layout): (64,NHWC) or (3,NCHW s1); got Cout=%d", Cout);
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    if (!out_nchw) WU_REQUIRE(((uintptr_t)y % 16) == 0 && (ldy * esz) % 16 == 0 && ldy >= Cout, "conv3x3_c3_fwd: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const int grid = grid_cap((long long)N * Ho * Wo, 256, 256 * 32);
+#define C3_LAUNCH(T, CO, ST, NCHW) hipLaunchKernelGGL((conv3x3_c3_fwd_kernel<T, CO, ST, NCHW>), dim3(grid), dim3(256), 0, s, x_nchw, w_oihw, bias, inv_sigma, y, ldy, N, H, W, act)
+    if (out_nchw) C3_LAUNCH(float, 3, 1, true);
+    else if (dtype == WU_BF16) { if (stride == 1) C3_LAUNCH(bf16_t, 64, 1, false); else C3_LAUNCH(bf16_t, 64, 2, false); }
+    else { if (stride == 1) C3_LAUNCH(float, 64, 1, false); else C3_LAUNCH(float, 64, 2, false); }
+#undef C3_LAUNCH
+    WU_LAUNCH_CHECK("conv3x3_c3_fwd");
+    return 0;
+}
+
+extern "C" int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy, int dy_nchw, const void* y, int ldy_,
+                                   int act, float* dw_oihw, float* dbias, int N, int H, int W, int Cout, int stride,
+                                   int accumulate, int dtype, void* stream) {
+    WU_REQUIRE(stride == 1 || stride == 2, "conv3x3_c3_wgrad: stride");
+    WU_REQUIRE(Cout > 0 && dw_oihw, "conv3x3_c3_wgrad: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        hipMemsetAsync(dw_oihw, 0, (size_t)Cout * 27 * sizeof(float), s);
+        if (dbias) hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
+    }
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    dim3 grid(grid_cap((long long)N * Ho * Wo, 64, 1024), cdiv(Cout, 64));
+#define C3W(T, ST, NCHW) hipLaunchKernelGGL((conv3x3_c3_wgrad_kernel<T, ST, NCHW>), grid, dim3(256), 0, s, x_nchw, dy, lddy, y, ldy_, act, dw_oihw, dbias, N, H, W, Cout)
+    if (dy_nchw) { if (stride == 1) C3W(float, 1, true); else C3W(float, 2, true); }
+    else if (dtype == WU_BF16) { if (stride == 1) C3W(bf16_t, 1, false); else C3W(bf16_t, 2, false); }
+    else { if (stride == 1) C3W(float, 1, false); else C3W(float, 2, false); }
+#undef C3W
+    WU_LAUNCH_CHECK("conv3x3_c3_wgrad");
+    return 0;
+}
+
+extern "C" int wu_conv3x3_c3_dgrad(const void* dy, int lddy, int dy_nchw, const void* y, int ldy_, int act,
+                                   const float* w_oihw, const float* inv_sigma, float* dx_nchw, int N, int H, int W,
+                                   int Cout, int stride, int accumulate, int dtype, void* stream) {
+    WU_REQUIRE(stride == 1 || stride == 2, "conv3x3_c3_dgrad: stride");
+    WU_REQUIRE(Cout > 0 && Cout <= 64, "conv3x3_c3_dgrad: Cout");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_cap((long long)N * H * W, 256, 256 * 32);
+    const size_t lds = (size_t)27 * Cout * sizeof(float);
+#define C3D(T, ST, NCHW) hipLaunchKernelGGL((conv3x3_c3_dgrad_kernel<T, ST, NCHW>), dim3(grid), dim3(256), lds, s, dy, lddy, y, ldy_, act, w_oihw, inv_sigma, dx_nchw, N, H, W, Cout, accumulate)
+    if (dy_nchw) { if (stride == 1) C3D(float, 1, true); else C3D(float, 2, true); }
+    else if (dtype == WU_BF16) { if (stride == 1) C3D(bf16_t, 1, false); else C3D(bf16_t, 2, false); }
+    else { if (stride == 1) C3D(float, 1, false); else C3D(float, 2, false); }
+#undef C3D
+    WU_LAUNCH_CHECK("conv3x3_c3_dgrad");
+    return 0;
+}
+
+extern "C" int wu_conv1x1_tanh_fwd(const void* x, int ldx, const float* w, const float* bias, float* out_nchw,
+                                   int N, int H, int W, int Cin, int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    const int E = 16 / esz;
+    const int LP = Cin / E;
+    WU_REQUIRE(Cin % E == 0 && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0, "conv1x1_tanh_fwd: Cin=%d unsupported", Cin);
+    WU_REQUIRE(((uintptr_t)x % 16) == 0 && (ldx * esz) % 16 == 0 && bias, "conv1x1_tanh_fwd: alignment/bias");
+    const int grid = grid_cap((long long)N * H * W, 256 / LP, 256 * 16);
+    if (dtype == WU_BF16) hipLaunchKernelGGL(conv1x1_tanh_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, w, bias, out_nchw, N, H * W, Cin);
+    else hipLaunchKernelGGL(conv1x1_tanh_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, w, bias, out_nchw, N, H * W, Cin);
+    WU_LAUNCH_CHECK("conv1x1_tanh_fwd");
+    return 0;
+}
+
+extern "C" int wu_conv1x1_tanh_bwd(const float* dout_nchw, const float* out_nchw, const void* x, int ldx, const float* w,
+                                   void* dx, int lddx, float* dw, float* dbias, int N, int H, int W, int Cin,
+                                   int accumulate, int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    const int E = 16 / esz;
+    const int LP = Cin / E;
+    WU_REQUIRE(Cin == 64, "conv1x1_tanh_bwd: Cin must be 64 (got %d)", Cin);
+    WU_REQUIRE(((uintptr_t)x % 16) == 0 && (ldx * esz) % 16 == 0 && ((uintptr_t)dx % 16) == 0 && (lddx * esz) % 16 == 0, "conv1x1_tanh_bwd: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        hipMemsetAsync(dw, 0, (size_t)3 * Cin * sizeof(float), s);
+        hipMemsetAsync(dbias, 0, 3 * sizeof(float), s);
+    }
+    const int grid = grid_cap((long long)N * H * W, 256 / LP, 1024);
+    if (dtype == WU_BF16) hipLaunchKernelGGL(conv1x1_tanh_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, dout_nchw, out_nchw, (const bf16_t*)x, ldx, w, (bf16_t*)dx, lddx, dw, dbias, N, H * W, Cin);
+    else hipLaunchKernelGGL(conv1x1_tanh_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, dout_nchw, out_nchw, (const float*)x, ldx, w, (float*)dx, lddx, dw, dbias, N, H * W, Cin);
+    WU_LAUNCH_CHECK("conv1x1_tanh_bwd");
+    return 0;
+}

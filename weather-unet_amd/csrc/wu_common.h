@@ -1,0 +1,121 @@
+// Shared device/host helpers for libwu_kernels.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/wu_kernels.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing ---------------------------------------------------------------------------
+extern thread_local char g_wu_err[256];
+#define WU_FAIL(code, ...)                                   \
+    do {                                                     \
+        snprintf(g_wu_err, sizeof(g_wu_err), __VA_ARGS__);   \
+        return (code);                                       \
+    } while (0)
+#define WU_REQUIRE(cond, ...) \
+    do {                      \
+        if (!(cond)) WU_FAIL(-1, __VA_ARGS__); \
+    } while (0)
+#define WU_LAUNCH_CHECK(name)                                                        \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) WU_FAIL((int)e_, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- profiling hooks (wu_prof.hip) --------------------------------------------------------------
+void wu_prof_pre(int family, hipStream_t s);
+void wu_prof_post(int family, hipStream_t s, double flops, double bytes);
+
+// ---- bf16 <-> f32 -------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    // plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even, NaN preserved)
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int kPer16B = 4;
+    __device__ static __forceinline__ float load(const float* p) { return *p; }
+    __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct ElemTraits<bf16_t> {
+    static constexpr int kPer16B = 8;
+    __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// unpack a 16-byte chunk into floats (4 for f32, 8 for bf16) and back
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& v, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* f);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
+    return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+}
+
+// activation-derivative gate: g * act'(y)   (ReLU: nets.py:21,23; LeakyReLU(0.2): nets.py:32)
+__device__ __forceinline__ float act_gate(float g, float y, int act) {
+    if (act == WU_ACT_RELU) return y > 0.f ? g : 0.f;
+    if (act == WU_ACT_LEAKY) return y > 0.f ? g : 0.2f * g;
+    return g;
+}
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == WU_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == WU_ACT_LEAKY) return v > 0.f ? v : 0.2f * v;
+    return v;
+}
+template <typename T> __device__ __forceinline__ uint4 gate16(const uint4& g, const uint4& y, int act) {
+    constexpr int n = ElemTraits<T>::kPer16B;
+    float gf[n], yf[n];
+    unpack16<T>(g, gf);
+    unpack16<T>(y, yf);
+#pragma unroll
+    for (int i = 0; i < n; ++i) gf[i] = act_gate(gf[i], yf[i], act);
+    return pack16<T>(gf);
+}
+
+// ---- XCD-aware block remap ------------------------------------------------------------------------
+// Blocks are dealt round-robin over the 8 XCDs (private 4 MiB L2 each).  Remap so each XCD owns a
+// contiguous range of logical tile ids: neighbouring tiles (shared halos / same input tile for
+// several Cout tiles) then hit the same L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// ---- counter-based RNG for dropout ----------------------------------------------------------------
+// 64-bit mix (splitmix64 finaliser) of (seed, counter); 16 bits per element, 4 elements per call.
+__host__ __device__ __forceinline__ uint64_t wu_mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// keep decision for element `idx` (a linear NCHW index of the dropout tensor): 16-bit uniform < thr
+__host__ __device__ __forceinline__ uint64_t wu_rand4(uint64_t seed, uint64_t group) {
+    return wu_mix64(seed * 0x9E3779B97F4A7C15ull + group + 0x632BE59BD9B4E019ull);
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,77 @@
+"""ctypes binding of libwu_kernels.so -- the C ABI declared in include/wu_kernels.h.
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, the product
+raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+import ctypes
+import os
+
+from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_uint64, c_void_p, POINTER
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libwu_kernels.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+FAM_CONV_MFMA, FAM_WGRAD, FAM_ALL = 1, 2, 255
+
+P, I, F, U64, SZ = c_void_p, c_int, c_float, c_uint64, c_size_t
+
+# name -> (restype, argtypes); mirrors include/wu_kernels.h one to one
+SIGNATURES = {
+    "wu_last_error": (c_char_p, []),
+    "wu_version": (I, []),
+    "wu_pack_conv3x3": (I, [P, P, P, I, I, P, I, P]),
+    "wu_conv3x3_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P, I, I, I, P]),
+    "wu_conv3x3_wgrad_workspace": (SZ, [I, I, I, I, I, I, I]),
+    "wu_conv3x3_wgrad": (I, [P, I, P, I, P, I, I, P, P, P, SZ, I, I, I, I, I, I, I, I, P]),
+    "wu_conv3x3_s2_dgrad_workspace": (SZ, [I, I, I, I, I]),
+    "wu_conv3x3_s2_dgrad": (I, [P, I, P, I, I, P, P, I, P, SZ, I, I, I, I, I, I, P]),
+    "wu_conv3x3_c3_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "wu_conv3x3_c3_wgrad": (I, [P, P, I, I, P, I, I, P, P, I, I, I, I, I, I, I, P]),
+    "wu_conv3x3_c3_dgrad": (I, [P, I, I, P, I, I, P, P, P, I, I, I, I, I, I, I, P]),
+    "wu_conv1x1_tanh_fwd": (I, [P, I, P, P, P, I, I, I, I, I, P]),
+    "wu_conv1x1_tanh_bwd": (I, [P, P, P, I, P, P, I, P, P, I, I, I, I, I, I, P]),
+    "wu_maxpool2_fwd": (I, [P, I, P, I, I, I, I, I, I, P]),
+    "wu_maxpool2_bwd": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, P]),
+    "wu_adain_stats": (I, [P, I, P, P, I, I, I, I, F, I, P]),
+    "wu_adain_upcat_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, F, U64, I, P]),
+    "wu_adain_upcat_bwd": (I, [P, I, P, I, P, P, P, I, P, P, P, P, I, I, I, I, F, U64, I, P]),
+    "wu_dropout_mask": (I, [P, I, I, I, I, F, U64, P]),
+    "wu_sumpool_fwd": (I, [P, I, P, I, I, I, I, I, P]),
+    "wu_sumpool_bwd": (I, [P, P, I, I, I, I, I, I, P]),
+    "wu_nhwc_to_nchw_f32": (I, [P, I, P, I, I, I, I, I, P]),
+    "wu_nchw_f32_to_nhwc": (I, [P, P, I, I, I, I, I, I, P]),
+    "wu_prof_begin": (I, [I, I]),
+    "wu_prof_end": (I, [POINTER(c_int), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built -- no silent fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python weather-unet_amd/wu/_build.py` "
+                "(or __graft_entry__.build()).  There is no CPU / PyTorch fallback for the hot path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().wu_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on a non-zero return."""
+    check(getattr(load(), name)(*args), name)

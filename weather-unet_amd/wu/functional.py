@@ -1,0 +1,382 @@
+"""torch.autograd.Function wrappers around libwu_kernels.so.
+
+The reference defines no custom backward (everything is torch.autograd, t_cls_train.py:272,307);
+here every hot op has a hand-written HIP forward and backward, glued into autograd so that
+``loss.backward()`` / ``torch.optim.Adam`` keep working unchanged on the reference's parameters
+(fp32, OIHW, same state-dict keys).
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from .layout import (as_nhwc, dtype_code, empty_nhwc, nhwc_ld, require_cuda, stream_ptr, torch_dtype)
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = _lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_LEAKY
+
+# ----------------------------------------------------------------------------------------------
+# workspaces (caller-owned, as the C ABI requires): one growable byte buffer per device
+# ----------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def workspace(nbytes, device):
+    key = (device.type, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _grad_nhwc(g, code):
+    """Incoming gradient -> NHWC storage of the compute dtype (no copy when it already is)."""
+    return as_nhwc(g, code)
+
+
+# ----------------------------------------------------------------------------------------------
+# packed weights
+# ----------------------------------------------------------------------------------------------
+class PackedConv:
+    """[tap][Cout][Cin] (forward) and [tap'][Cin][Cout] (data-gradient) MFMA operand images of one
+    OIHW fp32 weight, cached on (storage, version, dtype) so a weight is repacked once per update."""
+
+    def __init__(self):
+        self.key = None
+        self.w_fwd = None
+        self.w_dgrad = None
+
+    def get(self, weight, code):
+        key = (weight.data_ptr(), weight._version, code, tuple(weight.shape))
+        if key != self.key:
+            cout, cin = weight.shape[:2]
+            tdt = torch_dtype(code)
+            w = weight.detach()
+            if not w.is_contiguous():
+                w = w.contiguous()
+            self.w_fwd = torch.empty((9, cout, cin), dtype=tdt, device=weight.device)
+            self.w_dgrad = torch.empty((9, cin, cout), dtype=tdt, device=weight.device)
+            _lib.call("wu_pack_conv3x3", w.data_ptr(), self.w_fwd.data_ptr(), self.w_dgrad.data_ptr(),
+                      cout, cin, None, code, stream_ptr())
+            self.key = key
+        return self.w_fwd, self.w_dgrad
+
+
+# ----------------------------------------------------------------------------------------------
+# conv3x3 (+bias +activation), MFMA implicit GEMM        nets.py:18-33
+# ----------------------------------------------------------------------------------------------
+class Conv3x3Fn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, packed, stride, act, out):
+        require_cuda(x, "conv3x3")
+        code = dtype_code(x)
+        n, cin, h, w = x.shape
+        cout = weight.shape[0]
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        w_fwd, w_dgrad = packed.get(weight, code)
+        if out is None:
+            y = empty_nhwc(n, cout, ho, wo, x.dtype, x.device)
+        else:
+            assert tuple(out.shape) == (n, cout, ho, wo) and out.dtype == x.dtype
+            y = out.detach()
+        _lib.call("wu_conv3x3_fwd", x.data_ptr(), nhwc_ld(x), w_fwd.data_ptr(),
+                  bias.data_ptr() if bias is not None else None, y.data_ptr(), nhwc_ld(y),
+                  n, h, w, cin, cout, stride, act, None, 0, 0, code, stream_ptr())
+        ctx.save_for_backward(x, y, w_dgrad)
+        ctx.meta = (stride, act, code, tuple(weight.shape), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, w_dgrad = ctx.saved_tensors
+        stride, act, code, wshape, has_bias = ctx.meta
+        n, cin, h, w = x.shape
+        cout = wshape[0]
+        ho, wo = y.shape[2], y.shape[3]
+        gy = _grad_nhwc(gy, code)
+        s = stream_ptr()
+        gate = y if act != ACT_NONE else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_nhwc(n, cin, h, w, x.dtype, x.device)
+            if stride == 1:
+                _lib.call("wu_conv3x3_fwd", gy.data_ptr(), nhwc_ld(gy), w_dgrad.data_ptr(), None, dx.data_ptr(), nhwc_ld(dx),
+                          n, h, w, cout, cin, 1, ACT_NONE,
+                          gate.data_ptr() if gate is not None else None, nhwc_ld(gate) if gate is not None else 0, act,
+                          code, s)
+            else:
+                nbytes = _lib.load().wu_conv3x3_s2_dgrad_workspace(n, h, w, cout, code)
+                ws = workspace(nbytes, x.device)
+                _lib.call("wu_conv3x3_s2_dgrad", gy.data_ptr(), nhwc_ld(gy),
+                          gate.data_ptr() if gate is not None else None, nhwc_ld(gate) if gate is not None else 0, act,
+                          w_dgrad.data_ptr(), dx.data_ptr(), nhwc_ld(dx), ws.data_ptr(), ws.numel(),
+                          n, h, w, cin, cout, code, s)
+        dw = db = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
+            db = torch.empty((cout,), dtype=torch.float32, device=x.device) if has_bias else None
+            nbytes = _lib.load().wu_conv3x3_wgrad_workspace(n, h, w, cin, cout, stride, code)
+            ws = workspace(nbytes, x.device)
+            _lib.call("wu_conv3x3_wgrad", x.data_ptr(), nhwc_ld(x), gy.data_ptr(), nhwc_ld(gy),
+                      gate.data_ptr() if gate is not None else None, nhwc_ld(gate) if gate is not None else 0, act,
+                      dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
+                      n, h, w, cin, cout, stride, 0, code, s)
+        return dx, dw, db, None, None, None, None
+
+
+def conv3x3(x, weight, bias, packed, stride=1, act=ACT_NONE, out=None):
+    return Conv3x3Fn.apply(x, weight, bias, packed, stride, act, out)
+
+
+# ----------------------------------------------------------------------------------------------
+# conv3x3 with 3 input channels, straight from the NCHW fp32 image     cunet.py:45, disc.py:28
+# ----------------------------------------------------------------------------------------------
+class ConvC3Fn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, act, out_nchw, code):
+        require_cuda(x, "conv3x3_c3")
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        n, cin, h, w = x.shape
+        assert cin == 3
+        cout = weight.shape[0]
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        wt = weight.detach().contiguous()
+        if out_nchw:
+            y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
+            ldy = 0
+        else:
+            y = empty_nhwc(n, cout, ho, wo, torch_dtype(code), x.device)
+            ldy = cout
+        _lib.call("wu_conv3x3_c3_fwd", x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None, None,
+                  y.data_ptr(), ldy, 1 if out_nchw else 0, n, h, w, cout, stride, act, code, stream_ptr())
+        ctx.save_for_backward(x, y, wt)
+        ctx.meta = (stride, act, code, out_nchw, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, wt = ctx.saved_tensors
+        stride, act, code, out_nchw, has_bias = ctx.meta
+        n, _, h, w = x.shape
+        cout = wt.shape[0]
+        s = stream_ptr()
+        if out_nchw:
+            gy = gy.float().contiguous()
+            ldg = ldy = 0
+        else:
+            gy = _grad_nhwc(gy, code)
+            ldg, ldy = nhwc_ld(gy), nhwc_ld(y)
+        gate = y.data_ptr() if act != ACT_NONE else None
+        dw = torch.empty(wt.shape, dtype=torch.float32, device=x.device)
+        db = torch.empty((cout,), dtype=torch.float32, device=x.device) if has_bias else None
+        _lib.call("wu_conv3x3_c3_wgrad", x.data_ptr(), gy.data_ptr(), ldg, 1 if out_nchw else 0, gate, ldy, act,
+                  dw.data_ptr(), db.data_ptr() if db is not None else None, n, h, w, cout, stride, 0, code, s)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.call("wu_conv3x3_c3_dgrad", gy.data_ptr(), ldg, 1 if out_nchw else 0, gate, ldy, act,
+                      wt.data_ptr(), None, dx.data_ptr(), n, h, w, cout, stride, 0, code, s)
+        return dx, dw, db, None, None, None, None
+
+
+def conv3x3_c3(x, weight, bias, stride, act, out_nchw, code):
+    return ConvC3Fn.apply(x, weight, bias, stride, act, out_nchw, code)
+
+
+# ----------------------------------------------------------------------------------------------
+# MaxPool2d(2)        cunet.py:27,46,49,52
+# ----------------------------------------------------------------------------------------------
+class MaxPool2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        require_cuda(x, "maxpool2")
+        code = dtype_code(x)
+        n, c, h, w = x.shape
+        if h % 2 or w % 2:
+            raise ValueError(f"maxpool2: H and W must be even, got {h}x{w}")
+        y = empty_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
+        _lib.call("wu_maxpool2_fwd", x.data_ptr(), nhwc_ld(x), y.data_ptr(), nhwc_ld(y), n, h, w, c, code, stream_ptr())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        code = dtype_code(x)
+        n, c, h, w = x.shape
+        gy = _grad_nhwc(gy, code)
+        dx = empty_nhwc(n, c, h, w, x.dtype, x.device)
+        _lib.call("wu_maxpool2_bwd", x.data_ptr(), nhwc_ld(x), gy.data_ptr(), nhwc_ld(gy), None, 0,
+                  dx.data_ptr(), nhwc_ld(dx), n, h, w, c, code, stream_ptr())
+        return dx
+
+
+def maxpool2(x):
+    return MaxPool2Fn.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------
+# AdaIN statistics + fused apply / bilinear x2 / dropout / concat      utils.py:41-51, cunet.py:59-62
+# ----------------------------------------------------------------------------------------------
+def adain_stats(x, eps):
+    """{mean, rstd} per (n, c): (N, C, 2) fp32."""
+    code = dtype_code(x)
+    n, c, h, w = x.shape
+    stats = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+    scratch = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+    _lib.call("wu_adain_stats", x.data_ptr(), nhwc_ld(x), stats.data_ptr(), scratch.data_ptr(), n, h, w, c, float(eps), code, stream_ptr())
+    return stats
+
+
+class AdaINUpCatFn(Function):
+    """cat([dropout(upsample(adain(x, y))), skip], dim=1) with the skip tensor already resident in
+    channels [C, C+Cs) of `catbuf` (its producer wrote it there): only channels [0, C) are written."""
+
+    @staticmethod
+    def forward(ctx, x, y_std, y_mean, skip, catbuf, eps, p_drop, seed):
+        require_cuda(x, "adain_upcat")
+        code = dtype_code(x)
+        n, c, h, w = x.shape
+        cs = skip.shape[1]
+        assert tuple(catbuf.shape) == (n, c + cs, 2 * h, 2 * w) and catbuf.dtype == x.dtype
+        ld = nhwc_ld(catbuf)
+        esz = catbuf.element_size()
+        if skip.data_ptr() != catbuf.data_ptr() + c * esz or nhwc_ld(skip) != ld:
+            catbuf[:, c:].copy_(skip)          # producer did not write in place: one copy, still no torch.cat
+        stats = adain_stats(x, eps)
+        ys = y_std.detach().float().contiguous()
+        ym = y_mean.detach().float().contiguous()
+        out = catbuf.detach()
+        _lib.call("wu_adain_upcat_fwd", x.data_ptr(), nhwc_ld(x), stats.data_ptr(), ys.data_ptr(), ym.data_ptr(),
+                  out.data_ptr(), ld, n, h, w, c, float(p_drop), int(seed), code, stream_ptr())
+        ctx.save_for_backward(x, stats, ys)
+        ctx.meta = (code, float(p_drop), int(seed), cs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, stats, ys = ctx.saved_tensors
+        code, p_drop, seed, cs = ctx.meta
+        n, c, h, w = x.shape
+        g = _grad_nhwc(g, code)
+        dx = empty_nhwc(n, c, h, w, x.dtype, x.device)
+        d_std = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        d_mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        gtmp = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+        sums = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+        _lib.call("wu_adain_upcat_bwd", g.data_ptr(), nhwc_ld(g), x.data_ptr(), nhwc_ld(x), stats.data_ptr(), ys.data_ptr(),
+                  dx.data_ptr(), nhwc_ld(dx), d_std.data_ptr(), d_mean.data_ptr(), gtmp.data_ptr(), sums.data_ptr(),
+                  n, h, w, c, p_drop, seed, code, stream_ptr())
+        dskip = g[:, c:] if ctx.needs_input_grad[3] else None     # a channel-slice view: no copy
+        return dx, d_std, d_mean, dskip, None, None, None, None
+
+
+def adain_upcat(x, y_std, y_mean, skip, catbuf, eps, p_drop, seed):
+    return AdaINUpCatFn.apply(x, y_std, y_mean, skip, catbuf, eps, p_drop, seed)
+
+
+def dropout_mask(n, c, h2, w2, p_drop, seed, device):
+    """The keep-mask adain_upcat draws for (seed, p): (N, C, H2, W2) uint8 -- used by the parity tests to
+    feed the oracle the very same mask."""
+    m = torch.empty((n, c, h2, w2), dtype=torch.uint8, device=device)
+    _lib.call("wu_dropout_mask", m.data_ptr(), n, h2, w2, c, float(p_drop), int(seed), stream_ptr())
+    return m
+
+
+# ----------------------------------------------------------------------------------------------
+# conv_last (1x1) + tanh       cunet.py:39-40,80-82
+# ----------------------------------------------------------------------------------------------
+class Conv1x1TanhFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        require_cuda(x, "conv1x1_tanh")
+        code = dtype_code(x)
+        n, cin, h, w = x.shape
+        wt = weight.detach().reshape(3, cin).contiguous()
+        out = torch.empty((n, 3, h, w), dtype=torch.float32, device=x.device)
+        _lib.call("wu_conv1x1_tanh_fwd", x.data_ptr(), nhwc_ld(x), wt.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                  n, h, w, cin, code, stream_ptr())
+        ctx.save_for_backward(x, wt, out)
+        ctx.wshape = tuple(weight.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, wt, out = ctx.saved_tensors
+        code = dtype_code(x)
+        n, cin, h, w = x.shape
+        gout = gout.float().contiguous()
+        dx = empty_nhwc(n, cin, h, w, x.dtype, x.device)
+        dw = torch.empty((3, cin), dtype=torch.float32, device=x.device)
+        db = torch.empty((3,), dtype=torch.float32, device=x.device)
+        _lib.call("wu_conv1x1_tanh_bwd", gout.data_ptr(), out.data_ptr(), x.data_ptr(), nhwc_ld(x), wt.data_ptr(),
+                  dx.data_ptr(), nhwc_ld(dx), dw.data_ptr(), db.data_ptr(), n, h, w, cin, 0, code, stream_ptr())
+        return dx, dw.view(ctx.wshape), db
+
+
+def conv1x1_tanh(x, weight, bias):
+    return Conv1x1TanhFn.apply(x, weight, bias)
+
+
+# ----------------------------------------------------------------------------------------------
+# discriminator head: global sum pool        disc.py:32
+# ----------------------------------------------------------------------------------------------
+class SumPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        require_cuda(x, "sumpool")
+        code = dtype_code(x)
+        n, c, h, w = x.shape
+        feat = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        _lib.call("wu_sumpool_fwd", x.data_ptr(), nhwc_ld(x), feat.data_ptr(), n, h, w, c, code, stream_ptr())
+        ctx.meta = (code, tuple(x.shape), x.dtype)
+        return feat
+
+    @staticmethod
+    def backward(ctx, g):
+        code, (n, c, h, w), dt = ctx.meta
+        g = g.float().contiguous()
+        dx = empty_nhwc(n, c, h, w, dt, g.device)
+        _lib.call("wu_sumpool_bwd", g.data_ptr(), dx.data_ptr(), nhwc_ld(dx), n, h, w, c, code, stream_ptr())
+        return dx
+
+
+def sumpool(x):
+    return SumPoolFn.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------
+# layout boundary (differentiable): NCHW fp32 <-> NHWC compute dtype
+# ----------------------------------------------------------------------------------------------
+class ToNHWCFn(Function):
+    @staticmethod
+    def forward(ctx, x, code):
+        ctx.src = (x.dtype,)
+        return as_nhwc(x, code)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .layout import to_nchw_f32
+        return to_nchw_f32(as_nhwc(g, dtype_code(g) if g.dtype in (torch.float32, torch.bfloat16) else _lib.F32)).to(ctx.src[0]), None
+
+
+def to_nhwc(x, code):
+    if x.dtype == torch_dtype(code):
+        try:
+            nhwc_ld(x)
+            return x
+        except ValueError:
+            pass
+    return ToNHWCFn.apply(x, code)
+
+
+def adain_apply(x, y_std, y_mean, eps):
+    """Stand-alone AdaIN (reference utils.py:41-51) for callers that use the module outside the fused
+    U-Net path: torch ops on the GPU tensor (off the hot path; the U-Net uses adain_upcat)."""
+    xf = x.float()
+    n, c = xf.shape[:2]
+    flat = xf.reshape(n, c, -1)
+    x_std = (flat.var(dim=-1) + eps).sqrt().view(n, c, 1, 1)
+    x_mean = flat.mean(dim=-1).view(n, c, 1, 1)
+    out = (xf - x_mean) / x_std * y_std.view(n, c, 1, 1) + y_mean.view(n, c, 1, 1)
+    return out.to(x.dtype).contiguous(memory_format=torch.channels_last)
