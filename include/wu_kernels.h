@@ -118,7 +118,9 @@ int wu_maxpool2_bwd(const void* x, int ldx, const void* dy, int lddy, const void
                     void* dx, int lddx, int N, int H, int W, int C, int dtype, void* stream);
 
 /* AdaIN instance statistics (utils.py:34-39,47): per (n,c) over H*W: stats[n][c] = {mean, rstd}
- * with rstd = 1/sqrt(unbiased_var + eps).  `scratch` holds N*C*2 floats (zeroed by the call). */
+ * with rstd = 1/sqrt(unbiased_var + eps).  `scratch` holds N*C*2*WU_MAX_SPLITS floats (per-split partial
+ * sums, folded in fixed order: results are bitwise reproducible). */
+#define WU_MAX_SPLITS 16
 int wu_adain_stats(const void* x, int ldx, float* stats, float* scratch, int N, int H, int W, int C,
                    float eps, int dtype, void* stream);
 
@@ -132,7 +134,7 @@ int wu_adain_upcat_fwd(const void* x, int ldx, const float* stats, const float* 
                        int dtype, void* stream);
 /* Backward of the above.  dy: gradient of the concat buffer channels [0,C) (N,2H,2W) ld=lddy.
  * Produces dx (N,H,W,C) ld=lddx and d_y_std, d_y_mean (N,C) fp32.  `gtmp` (N*H*W*C floats) and
- * `sums` (N*C*2 floats) are caller-provided scratch. */
+ * `sums` (N*C*2*(1+WU_MAX_SPLITS) floats) are caller-provided scratch. */
 int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int ldx, const float* stats, const float* y_std,
                        void* dx, int lddx, float* d_y_std, float* d_y_mean, float* gtmp, float* sums,
                        int N, int H, int W, int C, float p_drop, uint64_t seed, int dtype, void* stream);

@@ -58,9 +58,11 @@ def cunet_param_shapes(num_classes):
     return shapes
 
 
-def make_cunet_params(num_classes=5, seed=0, gain=1.0):
-    """Deterministic fill: U(-b, b), b = gain*sqrt(3/fan_in) for weights (variance-preserving
-    with ReLU roughly halved, so activations stay O(1) through 15 convs), small biases."""
+def make_cunet_params(num_classes=5, seed=0, gain=0.6):
+    """Deterministic fill: conv weights U(-b, b), b = gain*sqrt(6/fan_in) (He-uniform x gain), small
+    biases.  gain = 0.6 keeps every activation O(1) through the 15 convs while the pre-tanh output stays
+    ~[-1, 1] (un-saturated tanh): a far harder parity case than nn.Conv2d's default init, under which the
+    activations collapse towards the biases (that case is covered by the *_default_init goldens)."""
     params = {}
     for k, shp in sorted(cunet_param_shapes(num_classes).items()):
         if k.endswith("emb.weight"):

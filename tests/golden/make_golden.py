@@ -121,6 +121,27 @@ def gen_train_case(tag, batch, size, seed):
     print(f"cunet_{tag}: train-mode out abs-max {y_ref.abs().max():.4f}")
 
 
+def gen_default_init_case(tag, batch, size, seed):
+    """The literal reading of north_star's "on fixed seeds": torch.manual_seed(seed) + the modules' DEFAULT
+    init (nn.Conv2d kaiming-uniform a=sqrt(5); cunet.py:41 leaves init_weight() commented out).  The build's
+    modules consume the CPU RNG in the same order, so the GPU box regenerates identical weights from the seed;
+    per-key checksums are stored so the test can prove that."""
+    torch.manual_seed(seed)
+    net = ref_cunet.Conditional_UNet(NC)
+    net.eval()
+    p = {k: v.clone() for k, v in net.state_dict().items()}
+    x, c = O.make_inputs(batch, size, NC, seed, True)
+    with torch.no_grad():
+        y_ref = net(x, c)
+        y_or = O.cunet_forward(p, x, c)
+    exact(y_ref, y_or, f"{tag} default-init output")
+    keys = sorted(p)
+    chk = np.array([[p[k].double().sum().item(), p[k].double().abs().sum().item(), p[k].reshape(-1)[0].item()] for k in keys])
+    np.savez_compressed(os.path.join(OUT, f"cunet_{tag}.npz"), meta=np.array([batch, size, 1, seed, NC]),
+                        out=y_ref.numpy(), keys=np.array(keys), checksums=chk)
+    print(f"cunet_{tag}: default-init out abs-max {y_ref.abs().max():.4f} std {y_ref.std():.5f}")
+
+
 def gen_disc(tag, batch, size, seed):
     p = O.make_sndisc_params(NC, seed)
     net = ref_disc.SNDisc(NC)
@@ -168,6 +189,8 @@ if __name__ == "__main__":
     gen_case("b1_32_soft", 1, 32, True, 2, True)
     gen_case("b3_96x_onehot", 3, 96, False, 3, False)
     gen_train_case("train_b2_64", 2, 64, 4)
+    gen_default_init_case("default_init_b2_128", 2, 128, 0)
+    gen_default_init_case("default_init_b2_64", 2, 64, 5)
     gen_disc("b2_64", 2, 64, 0)
     gen_disc("b3_128", 3, 128, 1)
     print("golden vectors written to", OUT)

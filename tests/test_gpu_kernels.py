@@ -280,8 +280,8 @@ def test_rejects_bad_arguments():
     """Error behaviour of the boundary: shape/alignment violations come back as RuntimeError, CPU tensors are
     refused (no fallback)."""
     from wu import functional as WF
-    x = torch.zeros(1, 48, 8, 8, device=_dev()).contiguous(memory_format=torch.channels_last)
+    x = torch.zeros(1, 40, 8, 8, device=_dev()).contiguous(memory_format=torch.channels_last)
     with pytest.raises(RuntimeError, match="Cin"):
-        WF.conv3x3(x, torch.zeros(64, 48, 3, 3, device=_dev()), None, WF.PackedConv(), 1, 0)
+        WF.conv3x3(x, torch.zeros(64, 40, 3, 3, device=_dev()), None, WF.PackedConv(), 1, 0)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         WF.maxpool2(torch.zeros(1, 64, 8, 8))

@@ -93,3 +93,24 @@ def test_sndisc(golden_dir, tag):
     with torch.no_grad():
         outs_e, _ = O.sndisc_forward(p2, x, c, train=False)
     assert np.abs(outs_e[0].numpy() - g["out_eval"]).max() <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("tag", ["default_init_b2_128", "default_init_b2_64"])
+def test_default_init_matches_reference(golden_dir, tag):
+    """torch.manual_seed(s) + the build's module constructor reproduces the REFERENCE's default-initialised
+    weights (same RNG consumption order: checksums captured from the reference), and the oracle on those
+    weights reproduces the reference's output."""
+    import cunet
+    g = _load(golden_dir, f"cunet_{tag}.npz")
+    batch, size, soft, seed, nc = [int(v) for v in g["meta"]]
+    torch.manual_seed(seed)
+    sd = cunet.Conditional_UNet(nc).state_dict()
+    keys = [str(k) for k in g["keys"]]
+    assert sorted(sd) == keys
+    for k, chk in zip(keys, g["checksums"]):
+        v = sd[k].double()
+        np.testing.assert_allclose([v.sum().item(), v.abs().sum().item(), sd[k].reshape(-1)[0].item()], chk, rtol=1e-12, atol=1e-12)
+    x, c = O.make_inputs(batch, size, nc, seed, True)
+    with torch.no_grad():
+        out = O.cunet_forward(sd, x, c)
+    assert np.abs(out.numpy() - g["out"]).max() <= TOL

@@ -100,17 +100,31 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int ldx, const T* _
 // =================================================================================================
 // AdaIN statistics (utils.py:34-39): shifted sums per (n,c), finalised to {mean, rstd}
 // =================================================================================================
+constexpr int kMaxSplits = 16;   // partial-sum slots per (n,c); scratch buffers are sized for this
+
+// deterministic block reduction: every pixel-lane writes its channel partials to LDS, then 128 threads
+// (64 channels x 2 quantities) add the pixel-lanes in fixed order.
+template <int PP>
+__device__ __forceinline__ void block_reduce_2x64(float (*red)[64][2], int tid, float* __restrict__ dst, int dst_stride) {
+    __syncthreads();
+    if (tid < 128) {
+        const int c = tid >> 1, j = tid & 1;
+        float s = 0.f;
+#pragma unroll 4
+        for (int p = 0; p < PP; ++p) s += red[p][c][j];
+        dst[(size_t)c * dst_stride + j] = s;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void adain_stats_kernel(const T* __restrict__ x, int ldx, float* __restrict__ scratch,
                                                           int HW, int C, int splits) {
     constexpr int E = ElemTraits<T>::kPer16B;
     constexpr int LP = 64 / E;         // lanes per pixel (64 channels per workgroup)
     constexpr int PP = 256 / LP;       // pixels per iteration
-    __shared__ float red[64][2];
+    __shared__ float red[PP][64][2];
     const int tid = threadIdx.x;
     const int cg = blockIdx.x, split = blockIdx.y, n = blockIdx.z;
-    if (tid < 128) red[tid >> 1][tid & 1] = 0.f;
-    __syncthreads();
     const int cl = tid % LP, pl = tid / LP;
     const T* base = x + (size_t)n * HW * ldx + cg * 64 + cl * E;
     float k[E], s1[E], s2[E], v[E];
@@ -130,21 +144,25 @@ __global__ __launch_bounds__(256) void adain_stats_kernel(const T* __restrict__ 
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        atomicAdd(&red[cl * E + e][0], s1[e]);
-        atomicAdd(&red[cl * E + e][1], s2[e]);
+        red[pl][cl * E + e][0] = s1[e];
+        red[pl][cl * E + e][1] = s2[e];
     }
-    __syncthreads();
-    if (tid < 128) atomicAdd(&scratch[((size_t)n * C + cg * 64 + (tid >> 1)) * 2 + (tid & 1)], red[tid >> 1][tid & 1]);
+    // scratch layout [n][c][split][2]
+    block_reduce_2x64<PP>(red, tid, scratch + (((size_t)n * C + cg * 64) * splits + split) * 2, splits * 2);
 }
 
 template <typename T>
 __global__ void adain_stats_final_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scratch,
-                                         float* __restrict__ stats, int N, int HW, int C, float eps) {
+                                         float* __restrict__ stats, int N, int HW, int C, float eps, int splits) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     const int n = i / C, c = i - n * C;
     const float k = ElemTraits<T>::load(x + (size_t)n * HW * ldx + c);
-    const float s1 = scratch[2 * i], s2 = scratch[2 * i + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int sp = 0; sp < splits; ++sp) {
+        s1 += scratch[((size_t)i * splits + sp) * 2];
+        s2 += scratch[((size_t)i * splits + sp) * 2 + 1];
+    }
     const float cnt = (float)HW;
     const float mean = k + s1 / cnt;
     const float var = fmaxf((s2 - s1 * s1 / cnt) / (cnt - 1.f), 0.f);   // unbiased (torch.var default), utils.py:36
@@ -222,11 +240,9 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_gather_kernel(
     float sy, float sx, uint32_t thr, float keep_scale, uint64_t seed) {
     constexpr int E = ElemTraits<T>::kPer16B;
     constexpr int LP = 64 / E, PP = 256 / LP;
-    __shared__ float red[64][2];
+    __shared__ float red[PP][64][2];
     const int tid = threadIdx.x;
     const int cg = blockIdx.x, n = blockIdx.z;
-    if (tid < 128) red[tid >> 1][tid & 1] = 0.f;
-    __syncthreads();
     const int cl = tid % LP, pl = tid / LP;
     const int c0 = cg * 64 + cl * E;
     const int H2 = 2 * H, W2 = 2 * W, HW = H * W;
@@ -281,11 +297,22 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_gather_kernel(
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        atomicAdd(&red[cl * E + e][0], s1[e]);
-        atomicAdd(&red[cl * E + e][1], s2[e]);
+        red[pl][cl * E + e][0] = s1[e];
+        red[pl][cl * E + e][1] = s2[e];
     }
-    __syncthreads();
-    if (tid < 128) atomicAdd(&sums[((size_t)n * C + cg * 64 + (tid >> 1)) * 2 + (tid & 1)], red[tid >> 1][tid & 1]);
+    // partials layout [n][c][split][2] (after the final [N][C][2] block)
+    const int splits = gridDim.y;
+    block_reduce_2x64<PP>(red, tid, sums + (((size_t)n * C + cg * 64) * splits + blockIdx.y) * 2, splits * 2);
+}
+
+// fold the per-split partials in fixed order: sums_final[n][c][2]
+__global__ void fold_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int NC2, int splits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC2) return;
+    const int nc = i >> 1, j = i & 1;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += part[((size_t)nc * splits + sp) * 2 + j];
+    out[i] = s;
 }
 
 // backward stage B: dx = y_std*rstd * (g' - mean(g') - xhat * sum(g'*xhat)/(HW-1));  d_y_mean = sum g',
@@ -344,10 +371,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void sumpool_fwd_kernel(const T* __restrict__ x, int ldx, float* __restrict__ feat, int HW, int C) {
     constexpr int E = ElemTraits<T>::kPer16B;
     constexpr int LP = 64 / E, PP = 256 / LP;
-    __shared__ float red[64];
+    __shared__ float red[PP][64];
     const int tid = threadIdx.x, cg = blockIdx.x, n = blockIdx.y;
-    if (tid < 64) red[tid] = 0.f;
-    __syncthreads();
     const int cl = tid % LP, pl = tid / LP;
     const T* base = x + (size_t)n * HW * ldx + cg * 64 + cl * E;
     float s[E], v[E];
@@ -359,9 +384,13 @@ __global__ __launch_bounds__(256) void sumpool_fwd_kernel(const T* __restrict__ 
         for (int e = 0; e < E; ++e) s[e] += v[e];
     }
 #pragma unroll
-    for (int e = 0; e < E; ++e) atomicAdd(&red[cl * E + e], s[e]);
+    for (int e = 0; e < E; ++e) red[pl][cl * E + e] = s[e];
     __syncthreads();
-    if (tid < 64) feat[(size_t)n * C + cg * 64 + tid] = red[tid];
+    if (tid < 64) {
+        float t = 0.f;
+        for (int p = 0; p < PP; ++p) t += red[p][tid];
+        feat[(size_t)n * C + cg * 64 + tid] = t;
+    }
 }
 
 template <typename T>
@@ -474,12 +503,11 @@ extern "C" int wu_adain_stats(const void* x, int ldx, float* stats, float* scrat
     const int HW = H * W;
     int splits = cdiv(1024, N * (C / 64));
     if (splits > cdiv(HW, 256)) splits = cdiv(HW, 256);
+    if (splits > kMaxSplits) splits = kMaxSplits;
     if (splits < 1) splits = 1;
-    hipError_t e = hipMemsetAsync(scratch, 0, (size_t)N * C * 2 * sizeof(float), s);
-    if (e != hipSuccess) WU_FAIL((int)e, "adain_stats: memset: %s", hipGetErrorString(e));
     DISPATCH_T(dtype, {
         hipLaunchKernelGGL(adain_stats_kernel<T>, dim3(C / 64, splits, N), dim3(256), 0, s, (const T*)x, ldx, scratch, HW, C, splits);
-        hipLaunchKernelGGL(adain_stats_final_kernel<T>, dim3(cdiv(N * C, 256)), dim3(256), 0, s, (const T*)x, ldx, scratch, stats, N, HW, C, eps);
+        hipLaunchKernelGGL(adain_stats_final_kernel<T>, dim3(cdiv(N * C, 256)), dim3(256), 0, s, (const T*)x, ldx, scratch, stats, N, HW, C, eps, splits);
     });
     WU_LAUNCH_CHECK("adain_stats");
     return 0;
@@ -513,13 +541,14 @@ extern "C" int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int l
     int splits = cdiv(2048, N * (C / 64));
     const int pp = 256 / (64 / (16 / esz));
     if (splits > cdiv(HW, pp)) splits = cdiv(HW, pp);
+    if (splits > kMaxSplits) splits = kMaxSplits;
     if (splits < 1) splits = 1;
-    hipError_t e = hipMemsetAsync(sums, 0, (size_t)N * C * 2 * sizeof(float), s);
-    if (e != hipSuccess) WU_FAIL((int)e, "adain_upcat_bwd: memset: %s", hipGetErrorString(e));
     const long long total = (long long)N * HW * (C / (16 / esz));
+    float* partials = sums + (size_t)N * C * 2;
     DISPATCH_T(dtype, {
         hipLaunchKernelGGL(adain_upcat_bwd_gather_kernel<T>, dim3(C / 64, splits, N), dim3(256), 0, s, (const T*)dy, lddy, (const T*)x, ldx,
-                           stats, gtmp, sums, H, W, C, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), seed);
+                           stats, gtmp, partials, H, W, C, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), seed);
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(N * C * 2, 256)), dim3(256), 0, s, partials, sums, N * C * 2, splits);
         hipLaunchKernelGGL(adain_upcat_bwd_apply_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, gtmp, sums, (const T*)x, ldx, stats, y_std,
                            (T*)dx, lddx, d_y_std, d_y_mean, N, HW, C);
     });

@@ -57,6 +57,10 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python weather-unet_amd/wu/_build.py` "
                 "(or __graft_entry__.build()).  There is no CPU / PyTorch fallback for the hot path.")
+        # torch bundles its own libamdhip64 (same soname as /opt/rocm's): import it FIRST so the dynamic
+        # loader binds this library to the HIP runtime instance torch initialises -- two runtime copies in
+        # one process do not share devices, streams or allocations.
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol

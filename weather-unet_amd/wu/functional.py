@@ -12,6 +12,7 @@ from . import _lib
 from .layout import (as_nhwc, dtype_code, empty_nhwc, nhwc_ld, require_cuda, stream_ptr, torch_dtype)
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = _lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_LEAKY
+MAX_SPLITS = 16     # WU_MAX_SPLITS of include/wu_kernels.h
 
 # ----------------------------------------------------------------------------------------------
 # workspaces (caller-owned, as the C ABI requires): one growable byte buffer per device
@@ -223,7 +224,7 @@ def adain_stats(x, eps):
     code = dtype_code(x)
     n, c, h, w = x.shape
     stats = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
-    scratch = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+    scratch = torch.empty((n, c, 2 * MAX_SPLITS), dtype=torch.float32, device=x.device)
     _lib.call("wu_adain_stats", x.data_ptr(), nhwc_ld(x), stats.data_ptr(), scratch.data_ptr(), n, h, w, c, float(eps), code, stream_ptr())
     return stats
 
@@ -263,7 +264,7 @@ class AdaINUpCatFn(Function):
         d_std = torch.empty((n, c), dtype=torch.float32, device=x.device)
         d_mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
         gtmp = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
-        sums = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+        sums = torch.empty((n, c, 2 * (1 + MAX_SPLITS)), dtype=torch.float32, device=x.device)
         _lib.call("wu_adain_upcat_bwd", g.data_ptr(), nhwc_ld(g), x.data_ptr(), nhwc_ld(x), stats.data_ptr(), ys.data_ptr(),
                   dx.data_ptr(), nhwc_ld(dx), d_std.data_ptr(), d_mean.data_ptr(), gtmp.data_ptr(), sums.data_ptr(),
                   n, h, w, c, p_drop, seed, code, stream_ptr())
