@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec, 256x256 cUNet training step (forward + backward [+ gradient all-reduce]
++ Adam) on N MI355X, bf16, synthetic data (BASELINE.json configs[1], B=32 per GPU).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; weak scaling (B per GPU fixed).  Rank 0 prints ONE JSON line with the metric, the
+roofline of the dominant kernel (timed live with hipEvents on the launch stream inside the timed region)
+and, at N=1, the CPU baseline (the oracle restatement, oracle/cunet_ref.py, timed on the host cores on a
+bounded sample: B=2 256x256 fp32 fwd+bwd).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "weather-unet_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+GFLOP_FWD_BWD_256 = 254.4      # conv MAC*2, fwd + dgrad + wgrad, per 256x256 image (SURVEY.md 8d / BASELINE.md 3)
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--fwd-only", action="store_true", help="inference forward (eval mode) instead of the training step")
+    return ap.parse_args()
+
+
+def cpu_baseline(size, iters=2, batch=2):
+    """The oracle (kind: 'port' = stock-PyTorch CPU restatement, bit-identical to the reference, oracle/cunet_ref.py)
+    timed on this box's host cores: fwd+bwd of the same loss, fp32."""
+    from oracle import cunet_ref as O
+    threads = torch.get_num_threads()
+    p = {k: v.clone().requires_grad_(True) for k, v in O.make_cunet_params(5, 0).items()}
+    x, c = O.make_inputs(batch, size, 5, 0, False)
+    times = []
+    for it in range(iters + 1):
+        for v in p.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        O.bench_loss(O.cunet_forward(p, x, c), x).backward()
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": round(batch / best, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle fwd+bwd, B={batch} {size}x{size} fp32, best of {iters} after 1 warm-up ({best:.2f} s/iter)"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...`")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import cunet
+    from wu import _lib
+    from wu.ddp import GradBucketReducer
+
+    torch.manual_seed(0)                       # same random-init weights on every rank
+    net = cunet.Conditional_UNet(5, precision=a.precision).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)      # a different synthetic shard per rank
+    x = (torch.rand((a.batch, 3, a.size, a.size), generator=g) * 2 - 1).to(dev)
+    c = torch.eye(5)[(torch.arange(a.batch) + rank * a.batch) % 5].to(dev)
+
+    if a.fwd_only:
+        net.eval()
+        reducer = opt = None
+    else:
+        net.train()                            # Dropout(0.3) active, as in training (cunet.py:28)
+        params = list(net.parameters())
+        reducer = GradBucketReducer(params, bucket_mb=12.0) if world > 1 else None
+        opt = torch.optim.Adam(params, lr=1e-4, betas=(0.0, 0.999), weight_decay=1e-4 / 20, fused=True)   # t_cls_train.py:184
+
+    def step():
+        if a.fwd_only:
+            with torch.no_grad():
+                return net(x, c)
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+        out = net(x, c)
+        loss = torch.mean(torch.abs(out - x))
+        loss.backward()
+        if reducer is not None:
+            reducer.finalize()
+        opt.step()
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    families = [_lib.FAM_CONV_FWD, _lib.FAM_WGRAD, _lib.FAM_CONV_DGRAD]
+    do_roof = (not a.no_roofline) and rank == 0
+    if do_roof:
+        _lib.prof_begin(families, 64 * a.steps + 64)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roof = None
+    if do_roof:
+        stats = {f: _lib.prof_query(f) for f in families}
+        _lib.prof_end()
+        dom = max(stats, key=lambda f: stats[f]["ms"])
+        s = stats[dom]
+        peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+        if s["launches"]:
+            ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": None, "kernel": _lib.FAMILY_KERNEL[dom], "launches": s["launches"],
+                    "avg_launch_ms": round(s["ms"] / s["launches"], 4),
+                    "algorithmic_gflop_per_launch": round(s["flops"] / s["launches"] / 1e9, 3),
+                    "share_of_step": round(s["ms"] / (dt * 1e3), 3),
+                    "other_kernels": {_lib.FAMILY_KERNEL[f]: {"ms_per_step": round(stats[f]["ms"] / a.steps, 3),
+                                                             "TFLOP/s": round(stats[f]["flops"] / max(stats[f]["ms"], 1e-9) / 1e9, 1)}
+                                      for f in families}}
+
+    if rank == 0:
+        imgs = a.batch * world * a.steps
+        value = imgs / dt
+        res = {
+            "metric": "images/sec 256x256 cUNet fwd+bwd" if not a.fwd_only else "images/sec cUNet forward (eval)",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": (f"cUNet {a.size}x{a.size} {a.precision} B={a.batch}/GPU, "
+                                    + ("forward only (eval)" if a.fwd_only else
+                                       "training step: fwd + bwd (dgrad+wgrad) + grad all-reduce + fused Adam; dropout p=0.3 on; "
+                                       "random-init weights, 5-class one-hot, loss mean|G(x,c)-x|")),
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                       "algorithmic_tflops": round(value * (GFLOP_FWD_BWD_256 if not a.fwd_only else GFLOP_FWD_BWD_256 / 3)
+                                                   * (a.size / 256) ** 2 / 1e3, 1)},
+        }
+        if roof is not None:
+            res["roofline"] = roof
+        if world == 1 and not a.no_cpu_baseline and not a.fwd_only:
+            res["cpu_baseline"] = cpu_baseline(a.size)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -152,14 +152,19 @@ int wu_nhwc_to_nchw_f32(const void* x, int ldx, float* y_nchw, int N, int H, int
 int wu_nchw_f32_to_nhwc(const float* x_nchw, void* y, int ldy, int N, int H, int W, int C, int dtype, void* stream);
 
 /* ---- instrumentation (bench.py roofline leg) -------------------------------------------------
- * When enabled, the launchers of kernel family `family` bracket each launch with hipEvents on the
- * launch stream (events from a fixed pool, no allocation after wu_prof_begin).  wu_prof_end
- * synchronises those events and returns launches / total ms / total algorithmic flops / bytes. */
-#define WU_FAM_CONV_MFMA 1
-#define WU_FAM_WGRAD 2
-#define WU_FAM_ALL 255
-int wu_prof_begin(int family, int max_launches);
-int wu_prof_end(int* launches, double* total_ms, double* total_flops, double* total_bytes);
+ * While enabled, the launchers of the kernel families in `family_mask` (bit f = family f) bracket each
+ * launch with hipEvents on the launch stream (events come from a pool created by wu_prof_begin; nothing
+ * is allocated per launch).  wu_prof_query synchronises on a family's events and returns its number of
+ * launches, summed duration, and summed ALGORITHMIC flops / bytes (DESIGN.md gives the per-launch
+ * formulas).  One kernel (template instantiation) per family, so the totals match one rocprofv3 row. */
+#define WU_FAM_CONV_FWD 1    /* conv3x3_mfma_kernel<T,1,false>: forward convs */
+#define WU_FAM_WGRAD 2       /* conv3x3_wgrad_kernel<T,1,P> */
+#define WU_FAM_CONV_DGRAD 3  /* conv3x3_mfma_kernel<T,1,true>: gated data-gradient pass */
+#define WU_FAM_CONV_S2 4     /* conv3x3_mfma_kernel<T,2,false>: discriminator stride-2 forward */
+#define WU_FAM_WGRAD_S2 5    /* conv3x3_wgrad_kernel<T,2,P> */
+int wu_prof_begin(unsigned family_mask, int max_launches);
+int wu_prof_query(int family, int* launches, double* total_ms, double* total_flops, double* total_bytes);
+int wu_prof_end(void);
 
 #ifdef __cplusplus
 }

@@ -307,8 +307,9 @@ extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, cons
     const long long grid = (long long)N * a.tiles_x * a.tiles_y * a.cout_tiles;
     WU_REQUIRE(grid < (1ll << 31), "conv3x3_fwd: grid too large");
     hipStream_t s = (hipStream_t)stream;
-    wu_prof_pre(WU_FAM_CONV_MFMA, s);
     const bool m = mask != nullptr;
+    const int fam = stride == 2 ? WU_FAM_CONV_S2 : (m ? WU_FAM_CONV_DGRAD : WU_FAM_CONV_FWD);
+    wu_prof_pre(fam, s);
     if (dtype == WU_BF16) {
         if (stride == 1) { if (m) launch_conv<bf16_t, 1, true>(a, lds, (int)grid, s); else launch_conv<bf16_t, 1, false>(a, lds, (int)grid, s); }
         else launch_conv<bf16_t, 2, false>(a, lds, (int)grid, s);
@@ -317,7 +318,7 @@ extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, cons
         else launch_conv<float, 2, false>(a, lds, (int)grid, s);
     }
     const double pix = (double)N * a.Ho * a.Wo;
-    wu_prof_post(WU_FAM_CONV_MFMA, s, 2.0 * pix * Cout * 9.0 * Cin,
+    wu_prof_post(fam, s, 2.0 * pix * Cout * 9.0 * Cin,
                  ((double)N * H * W * Cin * (m ? 2 : 1) + pix * Cout) * esz + 9.0 * Cin * Cout * esz);
     WU_LAUNCH_CHECK("conv3x3_mfma");
     return 0;

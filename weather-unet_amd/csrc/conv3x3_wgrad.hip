@@ -277,13 +277,14 @@ extern "C" int wu_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy
     a.halo_w = p.halo_w; a.halo_h = p.halo_h; a.halo_pix = p.halo_w * p.halo_h;
     const int grid = p.splits * a.co_blocks * a.ci_blocks;
     hipStream_t s = (hipStream_t)stream;
-    wu_prof_pre(WU_FAM_WGRAD, s);
+    const int fam = stride == 2 ? WU_FAM_WGRAD_S2 : WU_FAM_WGRAD;
+    wu_prof_pre(fam, s);
     if (dtype == WU_BF16) {
         if (stride == 1) launch_wgrad<bf16_t, 1, 256>(a, p.lds, grid, s); else launch_wgrad<bf16_t, 2, 128>(a, p.lds, grid, s);
     } else {
         if (stride == 1) launch_wgrad<float, 1, 128>(a, p.lds, grid, s); else launch_wgrad<float, 2, 64>(a, p.lds, grid, s);
     }
-    wu_prof_post(WU_FAM_WGRAD, s, 2.0 * N * a.Ho * a.Wo * 9.0 * Cin * Cout,
+    wu_prof_post(fam, s, 2.0 * N * a.Ho * a.Wo * 9.0 * Cin * Cout,
                  ((double)N * H * W * Cin + (double)N * a.Ho * a.Wo * Cout * (y ? 2 : 1)) * esz + 9.0 * Cin * Cout * 4);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(Cout * Cin, 256)), dim3(256), 0, s, a.slab, a.bslab, dw_oihw, dbias, p.splits, Cout, Cin, accumulate);
     WU_LAUNCH_CHECK("conv3x3_wgrad");

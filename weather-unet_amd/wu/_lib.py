@@ -13,7 +13,9 @@ LIB_PATH = os.path.join(_PKG, "lib", "libwu_kernels.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
-FAM_CONV_MFMA, FAM_WGRAD, FAM_ALL = 1, 2, 255
+FAM_CONV_FWD, FAM_WGRAD, FAM_CONV_DGRAD, FAM_CONV_S2, FAM_WGRAD_S2 = 1, 2, 3, 4, 5
+FAMILY_KERNEL = {1: "conv3x3_mfma_kernel<T,1,false> (forward)", 2: "conv3x3_wgrad_kernel<T,1>",
+                 3: "conv3x3_mfma_kernel<T,1,true> (dgrad)", 4: "conv3x3_mfma_kernel<T,2,false>", 5: "conv3x3_wgrad_kernel<T,2>"}
 
 P, I, F, U64, SZ = c_void_p, c_int, c_float, c_uint64, c_size_t
 
@@ -42,8 +44,9 @@ SIGNATURES = {
     "wu_sumpool_bwd": (I, [P, P, I, I, I, I, I, I, P]),
     "wu_nhwc_to_nchw_f32": (I, [P, I, P, I, I, I, I, I, P]),
     "wu_nchw_f32_to_nhwc": (I, [P, P, I, I, I, I, I, I, P]),
-    "wu_prof_begin": (I, [I, I]),
-    "wu_prof_end": (I, [POINTER(c_int), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "wu_prof_begin": (I, [ctypes.c_uint, I]),
+    "wu_prof_query": (I, [I, POINTER(c_int), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "wu_prof_end": (I, []),
 }
 
 _lib = None
@@ -79,3 +82,20 @@ def check(rc, what):
 def call(name, *args):
     """Call an int-returning entry point and raise on a non-zero return."""
     check(getattr(load(), name)(*args), name)
+
+
+def prof_begin(families, max_launches):
+    mask = 0
+    for f in families:
+        mask |= 1 << f
+    call("wu_prof_begin", mask, int(max_launches))
+
+
+def prof_query(family):
+    n, ms, fl, by = c_int(0), c_double(0), c_double(0), c_double(0)
+    call("wu_prof_query", family, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
+    return {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+
+
+def prof_end():
+    call("wu_prof_end")
