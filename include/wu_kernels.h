@@ -81,6 +81,12 @@ int wu_conv3x3_s2_dgrad(const void* dy, int lddy, const void* y, int ldy_, int a
                         void* dx, int lddx, void* workspace, size_t workspace_bytes,
                         int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
 
+/* Activation backward as one streaming pass: out = g * act'(y) (ReLU: y > 0; LeakyReLU: y > 0 ? 1 : 0.2),
+ * all three NHWC with their own pixel strides; `out` may alias `g`.  Lets both gradient GEMMs of a conv
+ * consume a pre-gated gradient (y == NULL / mask == NULL paths), which is what the LDS-DMA wgrad needs. */
+int wu_act_gate(const void* g, int ldg, const void* y, int ldy, void* out, int ldo,
+                int N, int H, int W, int C, int act, int dtype, void* stream);
+
 /* ---- thin layers (HBM-bound, no MFMA) -------------------------------------------------------
  * First conv of dconv_down1 / of the discriminator: Cin = 3 read straight from the NCHW fp32
  * image (cunet.py:45 via nets.py:20; disc.py:28 via nets.py:28-31).

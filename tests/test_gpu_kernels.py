@@ -47,6 +47,7 @@ CONV_SHAPES = [
     (2, 192, 64, 8, 8, 1),        # narrow image -> TW = 8 tiles; concat-sized Cin
     (1, 128, 128, 4, 4, 1),       # 4x4 bottleneck of a 32x32 input
     (3, 64, 64, 33, 35, 1),       # odd sizes
+    (2, 192, 128, 40, 72, 1),     # several tiles per split in the LDS-DMA wgrad, ragged in both directions
     (2, 64, 128, 16, 32, 2),      # discriminator stride-2
     (1, 128, 64, 10, 12, 2),
 ]
@@ -122,6 +123,47 @@ def test_conv3x3_backward(p, shape, act):
         if name != "dx" and p == "bf16":
             tol = 2e-3 * float(want.abs().max()) + 1e-3     # fp32-accumulated: tighter than the bf16-stored dx
         assert err <= tol, f"{name}: max-abs {err} (tol {tol}, |ref|max {want.abs().max().item()})"
+
+
+@pytest.mark.parametrize("p", DTYPES)
+@pytest.mark.parametrize("act", [1, 2])
+def test_conv3x3_gated_abi_paths(p, act):
+    """C ABI: the in-kernel gated variants (mask / y arguments) equal gate-then-GEMM through wu_act_gate."""
+    from wu import _lib, functional as WF
+    from wu.layout import empty_nhwc, nhwc_ld, precision_code, stream_ptr
+    code = precision_code(p)
+    n, cin, cout, h, w = 2, 64, 128, 12, 40
+    x = _nhwc(_round(_rand((n, cin, h, w), 71), p), p)
+    y = _nhwc(_round(_rand((n, cout, h, w), 72), p), p)          # stands for the stored activation
+    gy = _nhwc(_round(_rand((n, cout, h, w), 73), p), p)
+    wt = _round(_rand((cout, cin, 3, 3), 74, -0.1, 0.1), p).to(_dev())
+    w_fwd, w_dgrad = WF.PackedConv().get(wt, code)
+    s = stream_ptr()
+    gg = empty_nhwc(n, cout, h, w, _tdt(p), _dev())
+    _lib.call("wu_act_gate", gy.data_ptr(), nhwc_ld(gy), y.data_ptr(), nhwc_ld(y), gg.data_ptr(), nhwc_ld(gg), n, h, w, cout, act, code, s)
+    ref_gate = gy.float() * torch.where(y.float() > 0, torch.ones(()), torch.full((), 0.0 if act == 1 else 0.2)).to(_dev())
+    assert (gg.float() - ref_gate).abs().max().item() <= (0 if p == "fp32" else 4e-3)
+    dx = [empty_nhwc(n, cin, h, w, _tdt(p), _dev()) for _ in range(2)]
+    _lib.call("wu_conv3x3_fwd", gy.data_ptr(), nhwc_ld(gy), w_dgrad.data_ptr(), None, dx[0].data_ptr(), cin, n, h, w, cout, cin, 1, 0,
+              y.data_ptr(), nhwc_ld(y), act, code, s)
+    _lib.call("wu_conv3x3_fwd", gg.data_ptr(), nhwc_ld(gg), w_dgrad.data_ptr(), None, dx[1].data_ptr(), cin, n, h, w, cout, cin, 1, 0,
+              None, 0, 0, code, s)
+    assert torch.equal(dx[0], dx[1])
+    nbytes = _lib.load().wu_conv3x3_wgrad_workspace(n, h, w, cin, cout, 1, code)
+    ws = WF.workspace(nbytes, _dev())
+    dw = [torch.empty((cout, cin, 3, 3), device=_dev()) for _ in range(2)]
+    db = [torch.empty((cout,), device=_dev()) for _ in range(2)]
+    _lib.call("wu_conv3x3_wgrad", x.data_ptr(), cin, gy.data_ptr(), cout, y.data_ptr(), cout, act, dw[0].data_ptr(), db[0].data_ptr(),
+              ws.data_ptr(), ws.numel(), n, h, w, cin, cout, 1, 0, code, s)       # gated in-kernel (generic kernel)
+    _lib.call("wu_conv3x3_wgrad", x.data_ptr(), cin, gg.data_ptr(), cout, None, 0, 0, dw[1].data_ptr(), db[1].data_ptr(),
+              ws.data_ptr(), ws.numel(), n, h, w, cin, cout, 1, 0, code, s)       # pre-gated (LDS-DMA kernel for bf16)
+    tol = 1e-4 if p == "fp32" else 2e-3
+    assert (dw[0] - dw[1]).abs().max().item() <= tol * max(1.0, dw[1].abs().max().item())
+    assert (db[0] - db[1]).abs().max().item() <= tol * max(1.0, db[1].abs().max().item())
+    # accumulate != 0 adds into the existing gradient (autograd's .grad accumulation)
+    _lib.call("wu_conv3x3_wgrad", x.data_ptr(), cin, gg.data_ptr(), cout, None, 0, 0, dw[1].data_ptr(), db[1].data_ptr(),
+              ws.data_ptr(), ws.numel(), n, h, w, cin, cout, 1, 1, code, s)
+    assert (dw[1] - 2 * dw[0]).abs().max().item() <= 2 * tol * max(1.0, dw[0].abs().max().item())
 
 
 @pytest.mark.parametrize("p", DTYPES)

@@ -15,6 +15,7 @@
 // Partial blocks go to per-split slabs; a second kernel sums the slabs in fixed order (deterministic),
 // transposes to OIHW and optionally accumulates into .grad.  dbias rides along (ci-block 0 only).
 #include "wu_common.h"
+#include "wgrad_internal.h"
 
 namespace {
 
@@ -184,25 +185,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradArgs a
     }
 }
 
-// sum the split-K slabs in fixed order, transpose [tap][co][ci] -> OIHW, optional accumulate
+// sum the split-K slabs in fixed order (deterministic), transpose [tap][co][ci] -> OIHW, optional accumulate.
+// grid.y = tap; 4 independent partial sums keep 4 loads in flight per thread.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab, float* __restrict__ dw,
                                     float* __restrict__ dbias, int splits, int Cout, int Cin, int accumulate) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.y;
     const int total = Cout * Cin;
     if (idx < total) {
-        float s[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) s[t] = 0.f;
-        for (int k = 0; k < splits; ++k) {
-            const float* p = slab + (size_t)k * 9 * total + idx;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) s[t] += p[(size_t)t * total];
+        const size_t stride = (size_t)9 * total;
+        const float* p = slab + (size_t)t * total + idx;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = 0;
+        for (; k + 4 <= splits; k += 4) {
+            s0 += p[(size_t)k * stride]; s1 += p[(size_t)(k + 1) * stride];
+            s2 += p[(size_t)(k + 2) * stride]; s3 += p[(size_t)(k + 3) * stride];
         }
-        float* o = dw + (size_t)idx * 9;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) o[t] = accumulate ? o[t] + s[t] : s[t];
+        for (; k < splits; ++k) s0 += p[(size_t)k * stride];
+        const float s = (s0 + s1) + (s2 + s3);
+        float* o = dw + (size_t)idx * 9 + t;
+        *o = accumulate ? *o + s : s;
     }
-    if (dbias && idx < Cout) {
+    if (dbias && t == 0 && idx < Cout) {
         float b = 0.f;
         for (int k = 0; k < splits; ++k) b += bslab[(size_t)k * Cout + idx];
         dbias[idx] = accumulate ? dbias[idx] + b : b;
@@ -239,7 +243,7 @@ void launch_wgrad(const WgradArgs& a, size_t lds, int grid, hipStream_t s) {
     auto kern = conv3x3_wgrad_kernel<T, STRIDE, P>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
@@ -249,7 +253,12 @@ void launch_wgrad(const WgradArgs& a, size_t lds, int grid, hipStream_t s) {
 
 extern "C" size_t wu_conv3x3_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int stride, int dtype) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin % 64 || Cout % 64 || (stride != 1 && stride != 2)) return 0;
-    return wgrad_plan(N, H, W, Cin, Cout, stride, dtype).ws;
+    size_t ws = wgrad_plan(N, H, W, Cin, Cout, stride, dtype).ws;
+    if (wgrad_v2_eligible(H, W, Cin, Cout, stride, dtype, false)) {
+        const size_t w2 = wgrad_v2_plan(N, H, W, Cin, Cout).ws;
+        if (w2 > ws) ws = w2;
+    }
+    return ws;
 }
 
 extern "C" int wu_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy_, int act,
@@ -262,6 +271,23 @@ extern "C" int wu_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy
     WU_REQUIRE(N > 0 && H > 0 && W > 0 && Cin % 64 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0, "conv3x3_wgrad: Cin=%d Cout=%d must be multiples of 64", Cin, Cout);
     WU_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && (ldx * esz) % 16 == 0 && (lddy * esz) % 16 == 0 && ldx >= Cin && lddy >= Cout, "conv3x3_wgrad: alignment");
     if (y) WU_REQUIRE(((uintptr_t)y % 16) == 0 && (ldy_ * esz) % 16 == 0 && ldy_ >= Cout, "conv3x3_wgrad: y alignment");
+    hipStream_t s = (hipStream_t)stream;
+    const int fam = stride == 2 ? WU_FAM_WGRAD_S2 : WU_FAM_WGRAD;
+    const double flops = 2.0 * N * ((H - 1) / stride + 1) * ((W - 1) / stride + 1) * 9.0 * Cin * Cout;
+    const double bytes = ((double)N * H * W * Cin + (double)N * ((H - 1) / stride + 1) * ((W - 1) / stride + 1) * Cout * (y ? 2 : 1)) * esz + 9.0 * Cin * Cout * 4;
+    if (wgrad_v2_eligible(H, W, Cin, Cout, stride, dtype, y != nullptr)) {
+        const WgradV2Plan p2 = wgrad_v2_plan(N, H, W, Cin, Cout);
+        WU_REQUIRE(workspace && workspace_bytes >= p2.ws && ((uintptr_t)workspace % 16) == 0, "conv3x3_wgrad: workspace too small (%zu < %zu)", workspace_bytes, p2.ws);
+        WU_REQUIRE((size_t)H * W * (size_t)(ldx > lddy ? ldx : lddy) * 2 < (1ull << 31), "conv3x3_wgrad: image too large for 32-bit offsets");
+        float* slab = (float*)workspace;
+        float* bslab = dbias ? slab + (size_t)p2.splits * 9 * Cout * Cin : nullptr;
+        wu_prof_pre(fam, s);
+        wgrad_v2_launch(x, ldx, dy, lddy, slab, bslab, N, H, W, Cin, Cout, p2, s);
+        wu_prof_post(fam, s, flops, bytes);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(Cout * Cin, 256), 9), dim3(256), 0, s, slab, bslab, dw_oihw, dbias, p2.splits, Cout, Cin, accumulate);
+        WU_LAUNCH_CHECK("conv3x3_wgrad_v2");
+        return 0;
+    }
     const WPlan p = wgrad_plan(N, H, W, Cin, Cout, stride, dtype);
     WU_REQUIRE(workspace && workspace_bytes >= p.ws && ((uintptr_t)workspace % 16) == 0, "conv3x3_wgrad: workspace too small (%zu < %zu)", workspace_bytes, p.ws);
     WU_REQUIRE(p.lds <= 160 * 1024, "conv3x3_wgrad: LDS %zu", p.lds);
@@ -276,17 +302,14 @@ extern "C" int wu_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy
     a.splits = p.splits; a.co_blocks = Cout / 64; a.ci_blocks = Cin / 64;
     a.halo_w = p.halo_w; a.halo_h = p.halo_h; a.halo_pix = p.halo_w * p.halo_h;
     const int grid = p.splits * a.co_blocks * a.ci_blocks;
-    hipStream_t s = (hipStream_t)stream;
-    const int fam = stride == 2 ? WU_FAM_WGRAD_S2 : WU_FAM_WGRAD;
     wu_prof_pre(fam, s);
     if (dtype == WU_BF16) {
         if (stride == 1) launch_wgrad<bf16_t, 1, 256>(a, p.lds, grid, s); else launch_wgrad<bf16_t, 2, 128>(a, p.lds, grid, s);
     } else {
         if (stride == 1) launch_wgrad<float, 1, 128>(a, p.lds, grid, s); else launch_wgrad<float, 2, 64>(a, p.lds, grid, s);
     }
-    wu_prof_post(fam, s, 2.0 * N * a.Ho * a.Wo * 9.0 * Cin * Cout,
-                 ((double)N * H * W * Cin + (double)N * a.Ho * a.Wo * Cout * (y ? 2 : 1)) * esz + 9.0 * Cin * Cout * 4);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(Cout * Cin, 256)), dim3(256), 0, s, a.slab, a.bslab, dw_oihw, dbias, p.splits, Cout, Cin, accumulate);
+    wu_prof_post(fam, s, flops, bytes);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(Cout * Cin, 256), 9), dim3(256), 0, s, a.slab, a.bslab, dw_oihw, dbias, p.splits, Cout, Cin, accumulate);
     WU_LAUNCH_CHECK("conv3x3_wgrad");
     return 0;
 }

@@ -349,6 +349,23 @@ __global__ void adain_upcat_bwd_apply_kernel(const float* __restrict__ gtmp, con
     }
 }
 
+// out = g * act'(y): the activation backward of autograd as ONE streaming pass, so that the data-gradient
+// and weight-gradient GEMMs both consume a pre-gated gradient (no gating inside their staging loops).
+template <typename T>
+__global__ void act_gate_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ y, int ldy, T* __restrict__ out, int ldo,
+                                long long npix, int C, int act) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int cpp = C / E;
+    const long long total = npix * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpp);
+        const long long p = i / cpp;
+        const uint4 gv = *(const uint4*)(g + (size_t)p * ldg + ch * E);
+        const uint4 yv = *(const uint4*)(y + (size_t)p * ldy + ch * E);
+        *(uint4*)(out + (size_t)p * ldo + ch * E) = gate16<T>(gv, yv, act);
+    }
+}
+
 __global__ void dropout_mask_kernel(uint8_t* __restrict__ mask, int N, int H2, int W2, int C, uint32_t thr, uint64_t seed) {
     const long long total = (long long)N * H2 * W2 * C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -594,5 +611,17 @@ extern "C" int wu_nchw_f32_to_nhwc(const float* x_nchw, void* y, int ldy, int N,
     DISPATCH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(cdiv(H * W, 32), cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream,
                                          x_nchw, (T*)y, ldy, H * W, C));
     WU_LAUNCH_CHECK("nchw_to_nhwc");
+    return 0;
+}
+
+extern "C" int wu_act_gate(const void* g, int ldg, const void* y, int ldy, void* out, int ldo,
+                           int N, int H, int W, int C, int act, int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    WU_REQUIRE(C % (16 / esz) == 0 && ok16(g, ldg, esz) && ok16(y, ldy, esz) && ok16(out, ldo, esz), "act_gate: alignment");
+    const long long npix = (long long)N * H * W;
+    const long long total = npix * (C / (16 / esz));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(act_gate_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)g, ldg, (const T*)y, ldy, (T*)out, ldo, npix, C, act));
+    WU_LAUNCH_CHECK("act_gate");
     return 0;
 }

@@ -29,6 +29,7 @@ SIGNATURES = {
     "wu_conv3x3_wgrad": (I, [P, I, P, I, P, I, I, P, P, P, SZ, I, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_s2_dgrad_workspace": (SZ, [I, I, I, I, I]),
     "wu_conv3x3_s2_dgrad": (I, [P, I, P, I, I, P, P, I, P, SZ, I, I, I, I, I, I, P]),
+    "wu_act_gate": (I, [P, I, P, I, P, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_c3_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_c3_wgrad": (I, [P, P, I, I, P, I, I, P, P, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_c3_dgrad": (I, [P, I, I, P, I, I, P, P, P, I, I, I, I, I, I, I, P]),

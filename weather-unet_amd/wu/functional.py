@@ -95,20 +95,23 @@ class Conv3x3Fn(Function):
         ho, wo = y.shape[2], y.shape[3]
         gy = _grad_nhwc(gy, code)
         s = stream_ptr()
-        gate = y if act != ACT_NONE else None
+        if act != ACT_NONE:
+            # activation backward once, up front: both gradient GEMMs then read a pre-gated dY (the gated
+            # in-kernel paths of the C ABI stay available: mask / y arguments)
+            gg = empty_nhwc(n, cout, ho, wo, y.dtype, y.device)
+            _lib.call("wu_act_gate", gy.data_ptr(), nhwc_ld(gy), y.data_ptr(), nhwc_ld(y), gg.data_ptr(), nhwc_ld(gg),
+                      n, ho, wo, cout, act, code, s)
+            gy = gg
         dx = None
         if ctx.needs_input_grad[0]:
             dx = empty_nhwc(n, cin, h, w, x.dtype, x.device)
             if stride == 1:
                 _lib.call("wu_conv3x3_fwd", gy.data_ptr(), nhwc_ld(gy), w_dgrad.data_ptr(), None, dx.data_ptr(), nhwc_ld(dx),
-                          n, h, w, cout, cin, 1, ACT_NONE,
-                          gate.data_ptr() if gate is not None else None, nhwc_ld(gate) if gate is not None else 0, act,
-                          code, s)
+                          n, h, w, cout, cin, 1, ACT_NONE, None, 0, 0, code, s)
             else:
                 nbytes = _lib.load().wu_conv3x3_s2_dgrad_workspace(n, h, w, cout, code)
                 ws = workspace(nbytes, x.device)
-                _lib.call("wu_conv3x3_s2_dgrad", gy.data_ptr(), nhwc_ld(gy),
-                          gate.data_ptr() if gate is not None else None, nhwc_ld(gate) if gate is not None else 0, act,
+                _lib.call("wu_conv3x3_s2_dgrad", gy.data_ptr(), nhwc_ld(gy), None, 0, ACT_NONE,
                           w_dgrad.data_ptr(), dx.data_ptr(), nhwc_ld(dx), ws.data_ptr(), ws.numel(),
                           n, h, w, cin, cout, code, s)
         dw = db = None
@@ -117,8 +120,7 @@ class Conv3x3Fn(Function):
             db = torch.empty((cout,), dtype=torch.float32, device=x.device) if has_bias else None
             nbytes = _lib.load().wu_conv3x3_wgrad_workspace(n, h, w, cin, cout, stride, code)
             ws = workspace(nbytes, x.device)
-            _lib.call("wu_conv3x3_wgrad", x.data_ptr(), nhwc_ld(x), gy.data_ptr(), nhwc_ld(gy),
-                      gate.data_ptr() if gate is not None else None, nhwc_ld(gate) if gate is not None else 0, act,
+            _lib.call("wu_conv3x3_wgrad", x.data_ptr(), nhwc_ld(x), gy.data_ptr(), nhwc_ld(gy), None, 0, ACT_NONE,
                       dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
                       n, h, w, cin, cout, stride, 0, code, s)
         return dx, dw, db, None, None, None, None
