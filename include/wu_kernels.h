@@ -134,16 +134,19 @@ int wu_adain_stats(const void* x, int ldx, float* stats, float* scratch, int N, 
  * Dropout(p) (cunet.py:28,61,68,75) written into channels [0,C) of the concat buffer `y`
  * (N,2H,2W,*) ld=ldy; the skip tensor already lives in channels [C, ...) (torch.cat, cunet.py:62).
  * y_std / y_mean: (N,C) fp32 style statistics of utils.py:46,48.  p_drop == 0 -> eval mode.
- * Dropout keep-mask = counter RNG(seed, element index); keep scale 1/(1-p). */
+ * Dropout keep-mask = counter RNG(seed, element index); keep scale 1/(1-p).  `mask_bits` (may be NULL):
+ * N*2H*2W*(C / elements-per-16-B) bytes receiving one keep-bit per element, so the backward pass reads the
+ * mask instead of re-hashing (pass the same pointer, or NULL to regenerate from the seed). */
 int wu_adain_upcat_fwd(const void* x, int ldx, const float* stats, const float* y_std, const float* y_mean,
                        void* y, int ldy, int N, int H, int W, int C, float p_drop, uint64_t seed,
-                       int dtype, void* stream);
+                       uint8_t* mask_bits, int dtype, void* stream);
 /* Backward of the above.  dy: gradient of the concat buffer channels [0,C) (N,2H,2W) ld=lddy.
  * Produces dx (N,H,W,C) ld=lddx and d_y_std, d_y_mean (N,C) fp32.  `gtmp` (N*H*W*C floats) and
  * `sums` (N*C*2*(1+WU_MAX_SPLITS) floats) are caller-provided scratch. */
 int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int ldx, const float* stats, const float* y_std,
                        void* dx, int lddx, float* d_y_std, float* d_y_mean, float* gtmp, float* sums,
-                       int N, int H, int W, int C, float p_drop, uint64_t seed, int dtype, void* stream);
+                       int N, int H, int W, int C, float p_drop, uint64_t seed, const uint8_t* mask_bits,
+                       int dtype, void* stream);
 /* The keep-mask wu_adain_upcat_fwd draws for (seed, p): mask[n][c][h2][w2] (NCHW uint8), for tests. */
 int wu_dropout_mask(uint8_t* mask_nchw, int N, int H2, int W2, int C, float p_drop, uint64_t seed, void* stream);
 

@@ -281,6 +281,40 @@ def test_adain_upcat(p, shape, train):
 
 
 @pytest.mark.parametrize("p", DTYPES)
+def test_adain_upcat_bwd_mask_bits_vs_rehash(p):
+    """C ABI: backward reading the stored keep-bits == backward regenerating the mask from the seed."""
+    from wu import _lib, functional as WF
+    from wu.layout import empty_nhwc, nhwc_ld, precision_code, stream_ptr
+    code = precision_code(p)
+    n, c, h, w, cs, seed = 2, 128, 6, 10, 64, 424242
+    x = _nhwc(_round(_rand((n, c, h, w), 81, -1, 2), p), p)
+    g = _nhwc(_round(_rand((n, c + cs, 2 * h, 2 * w), 82), p), p)
+    ystd = _rand((n, c), 83, 0.5, 1.5).to(_dev())
+    ymean = _rand((n, c), 84).to(_dev())
+    stats = WF.adain_stats(x, 1e-5)
+    cat = empty_nhwc(n, c + cs, 2 * h, 2 * w, _tdt(p), _dev())
+    esz = 4 if p == "fp32" else 2
+    bits = torch.zeros(n * 4 * h * w * (c * esz // 16), dtype=torch.uint8, device=_dev())
+    s = stream_ptr()
+    _lib.call("wu_adain_upcat_fwd", x.data_ptr(), nhwc_ld(x), stats.data_ptr(), ystd.data_ptr(), ymean.data_ptr(),
+              cat.data_ptr(), nhwc_ld(cat), n, h, w, c, 0.3, seed, bits.data_ptr(), code, s)
+    keep_frac = sum(bin(int(b)).count("1") for b in bits[:4096].cpu().tolist()) / (4096 * (16 // esz))
+    assert abs(keep_frac - 0.7) < 0.03
+    res = []
+    for mb in (bits.data_ptr(), None):
+        dx = empty_nhwc(n, c, h, w, _tdt(p), _dev())
+        dstd, dmean = torch.empty((n, c), device=_dev()), torch.empty((n, c), device=_dev())
+        gtmp = torch.empty((n, h, w, c), device=_dev())
+        sums = torch.empty((n, c, 2 * (1 + WF.MAX_SPLITS)), device=_dev())
+        _lib.call("wu_adain_upcat_bwd", g.data_ptr(), nhwc_ld(g), x.data_ptr(), nhwc_ld(x), stats.data_ptr(), ystd.data_ptr(),
+                  dx.data_ptr(), nhwc_ld(dx), dstd.data_ptr(), dmean.data_ptr(), gtmp.data_ptr(), sums.data_ptr(),
+                  n, h, w, c, 0.3, seed, mb, code, s)
+        res.append((dx.clone(), dstd.clone(), dmean.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("p", DTYPES)
 def test_conv1x1_tanh(p):
     from wu import functional as WF
     n, cin, h, w = 2, 64, 12, 20

@@ -195,39 +195,63 @@ template <int E> __device__ __forceinline__ void keep_bits(uint64_t seed, uint64
     }
 }
 
+// load E consecutive floats (E = 4 or 8) with 16-B loads
+template <int E> __device__ __forceinline__ void ldf(const float* __restrict__ p, float* o) {
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+        const float4 v = *(const float4*)(p + e);
+        o[e] = v.x; o[e + 1] = v.y; o[e + 2] = v.z; o[e + 3] = v.w;
+    }
+}
+
+// grid: x = 256-thread chunks of one output row (W2 * C/E items), y = output rows (n, oh) (strided)
 template <typename T>
-__global__ void adain_upcat_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void adain_upcat_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ stats,
                                        const float* __restrict__ y_std, const float* __restrict__ y_mean,
                                        T* __restrict__ y, int ldy, int N, int H, int W, int C,
-                                       float sy, float sx, uint32_t thr, float keep_scale, uint64_t seed) {
+                                       float sy, float sx, uint32_t thr, float keep_scale, uint64_t seed,
+                                       uint8_t* __restrict__ mbits) {
     constexpr int E = ElemTraits<T>::kPer16B;
     const int cpp = C / E, H2 = 2 * H, W2 = 2 * W;
-    const long long total = (long long)N * H2 * W2 * cpp;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % cpp);
-        long long p = i / cpp;
-        const int ow = (int)(p % W2); p /= W2;
-        const int oh = (int)(p % H2);
-        const int n = (int)(p / H2);
-        const Lerp ly = src_index(oh, sy, H), lx = src_index(ow, sx, W);
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= W2 * cpp) return;
+    const int ow = idx / cpp, ch = idx - ow * cpp;
+    const Lerp lx = src_index(ow, sx, W);
+    for (int row = blockIdx.y; row < N * H2; row += gridDim.y) {
+        const int n = row / H2, oh = row - n * H2;
+        const Lerp ly = src_index(oh, sy, H);
         const T* b = x + (size_t)n * H * W * ldx + ch * E;
         float v00[E], v01[E], v10[E], v11[E], o[E];
         unpack16<T>(*(const uint4*)(b + (size_t)(ly.i0 * W + lx.i0) * ldx), v00);
         unpack16<T>(*(const uint4*)(b + (size_t)(ly.i0 * W + lx.i1) * ldx), v01);
         unpack16<T>(*(const uint4*)(b + (size_t)(ly.i1 * W + lx.i0) * ldx), v10);
         unpack16<T>(*(const uint4*)(b + (size_t)(ly.i1 * W + lx.i1) * ldx), v11);
+        const size_t opix = (size_t)row * W2 + ow;
         bool keep[E];
-        if (thr < 0x10000u) keep_bits<E>(seed, (uint64_t)((size_t)(n * H2 + oh) * W2 + ow) * C + ch * E, thr, keep);
+        if (thr < 0x10000u) {
+            keep_bits<E>(seed, (uint64_t)opix * C + ch * E, thr, keep);
+            if (mbits) {            // one byte per 16-B chunk: backward reads the mask instead of re-hashing
+                uint32_t bits = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) bits |= (keep[e] ? 1u : 0u) << e;
+                mbits[opix * cpp + ch] = (uint8_t)bits;
+            }
+        }
         const int sc = n * C + ch * E;
+        float st[2 * E], ys[E], ym[E];
+        ldf<2 * E>(stats + 2 * sc, st);
+        ldf<E>(y_std + sc, ys);
+        ldf<E>(y_mean + sc, ym);
+        const float w00 = ly.l0 * lx.l0, w01 = ly.l0 * lx.l1, w10 = ly.l1 * lx.l0, w11 = ly.l1 * lx.l1;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const float v = ly.l0 * (lx.l0 * v00[e] + lx.l1 * v01[e]) + ly.l1 * (lx.l0 * v10[e] + lx.l1 * v11[e]);
-            const float mean = stats[2 * (sc + e)], rstd = stats[2 * (sc + e) + 1];
-            float r = (v - mean) * (rstd * y_std[sc + e]) + y_mean[sc + e];   // utils.py:49-50
-            if (thr < 0x10000u) r = keep[e] ? r * keep_scale : 0.f;           // nn.Dropout(p) train mode
+            float r = (v - st[2 * e]) * (st[2 * e + 1] * ys[e]) + ym[e];     // utils.py:49-50
+            if (thr < 0x10000u) r = keep[e] ? r * keep_scale : 0.f;          // nn.Dropout(p) train mode
             o[e] = r;
         }
-        *(uint4*)(y + ((size_t)(n * H2 + oh) * W2 + ow) * ldy + ch * E) = pack16<T>(o);
+        (void)w00; (void)w01; (void)w10; (void)w11;
+        *(uint4*)(y + opix * ldy + ch * E) = pack16<T>(o);
     }
 }
 
@@ -237,7 +261,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void adain_upcat_bwd_gather_kernel(
     const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx, const float* __restrict__ stats,
     float* __restrict__ gtmp, float* __restrict__ sums, int H, int W, int C,
-    float sy, float sx, uint32_t thr, float keep_scale, uint64_t seed) {
+    float sy, float sx, uint32_t thr, float keep_scale, uint64_t seed, const uint8_t* __restrict__ mbits) {
     constexpr int E = ElemTraits<T>::kPer16B;
     constexpr int LP = 64 / E, PP = 256 / LP;
     __shared__ float red[PP][64][2];
@@ -245,14 +269,12 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_gather_kernel(
     const int cg = blockIdx.x, n = blockIdx.z;
     const int cl = tid % LP, pl = tid / LP;
     const int c0 = cg * 64 + cl * E;
+    const int cpp = C / E, chunk = c0 / E;
     const int H2 = 2 * H, W2 = 2 * W, HW = H * W;
-    float s1[E], s2[E], mean[E], rstd[E];
+    float s1[E], s2[E], st[2 * E];
+    ldf<2 * E>(stats + 2 * (n * C + c0), st);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        s1[e] = s2[e] = 0.f;
-        mean[e] = stats[2 * (n * C + c0 + e)];
-        rstd[e] = stats[2 * (n * C + c0 + e) + 1];
-    }
+    for (int e = 0; e < E; ++e) s1[e] = s2[e] = 0.f;
     const int per = (HW + gridDim.y - 1) / gridDim.y;
     const int p0 = blockIdx.y * per, p1 = min(HW, p0 + per);
     for (int p = p0 + pl; p < p1; p += PP) {
@@ -260,36 +282,60 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_gather_kernel(
         float g[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) g[e] = 0.f;
-        for (int i = max(0, 2 * yy - 2); i <= min(H2 - 1, 2 * yy + 3); ++i) {
+        // separable weights of the (at most 6 x 6) output pixels that interpolate from (yy, xx)
+        const int j0 = 2 * xx - 2, i0 = 2 * yy - 2;
+        float wxs[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int j = j0 + k;
+            float wv = 0.f;
+            if (j >= 0 && j < W2) {
+                const Lerp lx = src_index(j, sx, W);
+                wv = (lx.i0 == xx ? lx.l0 : 0.f) + (lx.i1 == xx ? lx.l1 : 0.f);
+            }
+            wxs[k] = wv;
+        }
+#pragma unroll
+        for (int ki = 0; ki < 6; ++ki) {
+            const int i = i0 + ki;
+            if (i < 0 || i >= H2) continue;
             const Lerp ly = src_index(i, sy, H);
             const float wy = (ly.i0 == yy ? ly.l0 : 0.f) + (ly.i1 == yy ? ly.l1 : 0.f);
             if (wy == 0.f) continue;
-            for (int j = max(0, 2 * xx - 2); j <= min(W2 - 1, 2 * xx + 3); ++j) {
-                const Lerp lx = src_index(j, sx, W);
-                const float wx = (lx.i0 == xx ? lx.l0 : 0.f) + (lx.i1 == xx ? lx.l1 : 0.f);
-                if (wx == 0.f) continue;
-                const size_t opix = (size_t)(n * H2 + i) * W2 + j;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (wxs[k] == 0.f) continue;
+                const size_t opix = (size_t)(n * H2 + i) * W2 + (j0 + k);
                 float d[E];
                 unpack16<T>(*(const uint4*)(dy + opix * lddy + c0), d);
-                float wgt = wy * wx;
+                const float wgt = wy * wxs[k];
                 if (thr < 0x10000u) {
-                    bool keep[E];
-                    keep_bits<E>(seed, (uint64_t)opix * C + c0, thr, keep);
-                    wgt *= keep_scale;
+                    if (mbits) {
+                        const uint32_t bits = mbits[opix * cpp + chunk];
 #pragma unroll
-                    for (int e = 0; e < E; ++e) g[e] += keep[e] ? wgt * d[e] : 0.f;
+                        for (int e = 0; e < E; ++e) g[e] += ((bits >> e) & 1u) ? wgt * d[e] : 0.f;
+                    } else {
+                        bool keep[E];
+                        keep_bits<E>(seed, (uint64_t)opix * C + c0, thr, keep);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) g[e] += keep[e] ? wgt * d[e] : 0.f;
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < E; ++e) g[e] += wgt * d[e];
                 }
             }
         }
+        if (thr < 0x10000u) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) g[e] *= keep_scale;
+        }
         float xv[E];
         unpack16<T>(*(const uint4*)(x + ((size_t)n * HW + p) * ldx + c0), xv);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             s1[e] += g[e];
-            s2[e] += g[e] * ((xv[e] - mean[e]) * rstd[e]);
+            s2[e] += g[e] * ((xv[e] - st[2 * e]) * st[2 * e + 1]);
         }
         float* gd = gtmp + ((size_t)n * HW + p) * C + c0;
 #pragma unroll
@@ -317,35 +363,38 @@ __global__ void fold_partials_kernel(const float* __restrict__ part, float* __re
 
 // backward stage B: dx = y_std*rstd * (g' - mean(g') - xhat * sum(g'*xhat)/(HW-1));  d_y_mean = sum g',
 // d_y_std = sum g'*xhat.
+// grid: x = 256-thread chunks of one image (HW * C/E items), y = image
 template <typename T>
-__global__ void adain_upcat_bwd_apply_kernel(const float* __restrict__ gtmp, const float* __restrict__ sums,
+__global__ __launch_bounds__(256) void adain_upcat_bwd_apply_kernel(const float* __restrict__ gtmp, const float* __restrict__ sums,
                                              const T* __restrict__ x, int ldx, const float* __restrict__ stats,
                                              const float* __restrict__ y_std, T* __restrict__ dx, int lddx,
                                              float* __restrict__ d_y_std, float* __restrict__ d_y_mean,
                                              int N, int HW, int C) {
     constexpr int E = ElemTraits<T>::kPer16B;
     const int cpp = C / E;
-    const long long total = (long long)N * HW * cpp;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % cpp);
-        const long long p = i / cpp;            // n*HW + pixel
-        const int n = (int)(p / HW);
+    const int n = blockIdx.y;
+    const float inv_hw = 1.f / (float)HW, inv_hw1 = 1.f / (float)(HW - 1);
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < HW * cpp; idx += gridDim.x * 256) {
+        const int pix = idx / cpp, ch = idx - pix * cpp;
+        const size_t p = (size_t)n * HW + pix;
         const int sc = n * C + ch * E;
-        float xv[E], o[E];
-        unpack16<T>(*(const uint4*)(x + (size_t)p * ldx + ch * E), xv);
-        const float* g = gtmp + (size_t)p * C + ch * E;
+        float xv[E], o[E], g[E], st[2 * E], sm[2 * E], ys[E];
+        unpack16<T>(*(const uint4*)(x + p * ldx + ch * E), xv);
+        ldf<E>(gtmp + p * C + ch * E, g);
+        ldf<2 * E>(stats + 2 * sc, st);
+        ldf<2 * E>(sums + 2 * sc, sm);
+        ldf<E>(y_std + sc, ys);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const float mean = stats[2 * (sc + e)], rstd = stats[2 * (sc + e) + 1];
-            const float S1 = sums[2 * (sc + e)], S2 = sums[2 * (sc + e) + 1];
+            const float mean = st[2 * e], rstd = st[2 * e + 1], S1 = sm[2 * e], S2 = sm[2 * e + 1];
             const float xh = (xv[e] - mean) * rstd;
-            o[e] = y_std[sc + e] * rstd * (g[e] - S1 / (float)HW - xh * S2 / (float)(HW - 1));
-            if (p % HW == 0) {
+            o[e] = ys[e] * rstd * (g[e] - S1 * inv_hw - xh * S2 * inv_hw1);
+            if (pix == 0) {
                 d_y_mean[sc + e] = S1;
                 d_y_std[sc + e] = S2;
             }
         }
-        *(uint4*)(dx + (size_t)p * lddx + ch * E) = pack16<T>(o);
+        *(uint4*)(dx + p * lddx + ch * E) = pack16<T>(o);
     }
 }
 
@@ -532,25 +581,29 @@ extern "C" int wu_adain_stats(const void* x, int ldx, float* stats, float* scrat
 
 extern "C" int wu_adain_upcat_fwd(const void* x, int ldx, const float* stats, const float* y_std, const float* y_mean,
                                   void* y, int ldy, int N, int H, int W, int C, float p_drop, uint64_t seed,
-                                  int dtype, void* stream) {
+                                  uint8_t* mask_bits, int dtype, void* stream) {
     const int esz = dtype == WU_BF16 ? 2 : 4;
     WU_REQUIRE(C % (16 / esz) == 0 && C <= ldx && C <= ldy && H > 1 && W > 1, "adain_upcat_fwd: bad shape");
     WU_REQUIRE(ok16(x, ldx, esz) && ok16(y, ldy, esz), "adain_upcat_fwd: alignment");
     WU_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "adain_upcat_fwd: p_drop");
     const float sy = (float)(H - 1) / (float)(2 * H - 1), sx = (float)(W - 1) / (float)(2 * W - 1);
-    const long long total = (long long)N * 4 * H * W * (C / (16 / esz));
-    DISPATCH_T(dtype, hipLaunchKernelGGL(adain_upcat_fwd_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
+    WU_REQUIRE(((uintptr_t)stats % 16) == 0 && ((uintptr_t)y_std % 16) == 0 && ((uintptr_t)y_mean % 16) == 0, "adain_upcat_fwd: stats alignment");
+    const int rows = N * 2 * H;
+    const dim3 grid(cdiv(2 * W * (C / (16 / esz)), 256), rows < 32768 ? rows : 32768);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(adain_upcat_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
                                          (const T*)x, ldx, stats, y_std, y_mean, (T*)y, ldy, N, H, W, C, sy, sx,
-                                         keep_thr(p_drop), 1.f / (1.f - p_drop), seed));
+                                         keep_thr(p_drop), 1.f / (1.f - p_drop), seed, mask_bits));
     WU_LAUNCH_CHECK("adain_upcat_fwd");
     return 0;
 }
 
 extern "C" int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int ldx, const float* stats, const float* y_std,
                                   void* dx, int lddx, float* d_y_std, float* d_y_mean, float* gtmp, float* sums,
-                                  int N, int H, int W, int C, float p_drop, uint64_t seed, int dtype, void* stream) {
+                                  int N, int H, int W, int C, float p_drop, uint64_t seed, const uint8_t* mask_bits,
+                                  int dtype, void* stream) {
     const int esz = dtype == WU_BF16 ? 2 : 4;
     WU_REQUIRE(C % 64 == 0 && H > 1 && W > 1, "adain_upcat_bwd: bad shape");
+    WU_REQUIRE(((uintptr_t)stats % 16) == 0 && ((uintptr_t)sums % 16) == 0 && ((uintptr_t)y_std % 16) == 0, "adain_upcat_bwd: stats alignment");
     WU_REQUIRE(ok16(x, ldx, esz) && ok16(dy, lddy, esz) && ok16(dx, lddx, esz) && ((uintptr_t)gtmp % 16) == 0, "adain_upcat_bwd: alignment");
     hipStream_t s = (hipStream_t)stream;
     const float sy = (float)(H - 1) / (float)(2 * H - 1), sx = (float)(W - 1) / (float)(2 * W - 1);
@@ -564,9 +617,9 @@ extern "C" int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int l
     float* partials = sums + (size_t)N * C * 2;
     DISPATCH_T(dtype, {
         hipLaunchKernelGGL(adain_upcat_bwd_gather_kernel<T>, dim3(C / 64, splits, N), dim3(256), 0, s, (const T*)dy, lddy, (const T*)x, ldx,
-                           stats, gtmp, partials, H, W, C, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), seed);
+                           stats, gtmp, partials, H, W, C, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), seed, mask_bits);
         hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(N * C * 2, 256)), dim3(256), 0, s, partials, sums, N * C * 2, splits);
-        hipLaunchKernelGGL(adain_upcat_bwd_apply_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, gtmp, sums, (const T*)x, ldx, stats, y_std,
+        hipLaunchKernelGGL(adain_upcat_bwd_apply_kernel<T>, dim3(grid_for((long long)HW * (C / (16 / esz)), 256, 1024), N), dim3(256), 0, s, gtmp, sums, (const T*)x, ldx, stats, y_std,
                            (T*)dx, lddx, d_y_std, d_y_mean, N, HW, C);
     });
     WU_LAUNCH_CHECK("adain_upcat_bwd");

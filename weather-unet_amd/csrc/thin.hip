@@ -130,6 +130,111 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_kernel(const float* __re
     }
 }
 
+// bf16 production path of the weight gradient above: dW[64 co][27 -> 32 k] = dY'^T [64 x P] * patch [P x 32] on the
+// matrix cores.  Per 256-pixel tile (linear pixel order, any image shape) the gated dY' tile and a per-pixel
+// 27-element patch row (bf16, padded to 32) are staged in LDS; both MFMA operands have the pixel (K) as their
+// slow index, so fragments come through ds_read_b64_tr_b16 as in conv3x3_wgrad.  4 waves split the 16 K-steps;
+// accumulators persist over a grid-stride loop of tiles, then one LDS reduction + fp32 atomics per workgroup.
+template <int STRIDE>
+__global__ __launch_bounds__(256) void conv3x3_c3_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, int lddy,
+                                                                    const bf16_t* __restrict__ y, int ldy, int act,
+                                                                    float* __restrict__ dw, float* __restrict__ dbias,
+                                                                    int N, int H, int W) {
+    __shared__ __attribute__((aligned(16))) char smem[256 * 128 + 256 * 64];
+    char* dy_lds = smem;                 // [256 px][64 co] bf16, 64-B halves swapped on odd pixel pairs
+    char* pa_lds = smem + 256 * 128;     // [256 px][32 k] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
+    const long long total = (long long)N * Ho * Wo;
+    const long long ntiles = (total + 255) / 256;
+    f32x16_t acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+    float bsum = 0.f;
+    const int g16 = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, h = g16 >> 1;
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long base = tile * 256;
+        // ---- dY' tile: 2048 16-B items ----
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int item = tid + 256 * k;
+            const int r = item >> 3, s = item & 7;
+            const long long pix = base + r;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (pix < total) {
+                v = *(const uint4*)(dy + (size_t)pix * lddy + s * 8);
+                if (y) v = gate16<bf16_t>(v, *(const uint4*)(y + (size_t)pix * ldy + s * 8), act);
+            }
+            *(uint4*)(dy_lds + r * 128 + ((s * 16) ^ (((r >> 1) & 1) << 6))) = v;
+        }
+        // ---- patch rows: thread = pixel ----
+        {
+            const long long pix = base + tid;
+            float pv[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) pv[k] = 0.f;
+            if (pix < total) {
+                const int ow = (int)(pix % Wo), oh = (int)((pix / Wo) % Ho), n = (int)(pix / ((long long)Wo * Ho));
+                const float* xn = x + (size_t)n * 3 * H * W;
+#pragma unroll
+                for (int k = 0; k < 27; ++k) {
+                    const int ci = k / 9, t = k % 9, ih = oh * STRIDE + t / 3 - 1, iw = ow * STRIDE + t % 3 - 1;
+                    if (ih >= 0 && ih < H && iw >= 0 && iw < W) pv[k] = xn[((size_t)ci * H + ih) * W + iw];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *(uint4*)(pa_lds + tid * 64 + c * 16) = pack16<bf16_t>(pv + 8 * c);
+        }
+        __syncthreads();
+        if (dbias) {
+            const int co = tid & 63, part = tid >> 6;
+            for (int r = part; r < 256; r += 4) bsum += bf16_to_f32(*(const bf16_t*)(dy_lds + r * 128 + ((co * 2) ^ (((r >> 1) & 1) << 6))));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ks = 4 * kk + wave;
+            const int r0 = 16 * ks + 8 * h + q;
+            const char* pb = pa_lds + r0 * 64 + (16 * (g16 & 1) + 4 * pp) * 2;
+            const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)pb);
+            const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pb + 4 * 64));
+            const uint4 bf = make_uint4(((const uint32_t*)&b0)[0], ((const uint32_t*)&b0)[1], ((const uint32_t*)&b1)[0], ((const uint32_t*)&b1)[1]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int cb = (32 * m + 16 * (g16 & 1) + 4 * pp) * 2;
+                const char* pa = dy_lds + r0 * 128 + (cb ^ (((q >> 1) & 1) << 6));
+                const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)pa);
+                const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pa + 4 * 128));
+                const uint4 af = make_uint4(((const uint32_t*)&a0)[0], ((const uint32_t*)&a0)[1], ((const uint32_t*)&a1)[0], ((const uint32_t*)&a1)[1]);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bf), acc[m], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- reduce the 4 waves through LDS, then one atomic per output element ----
+    float* red = (float*)smem;           // [4 waves][32 regs][64 lanes]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[(wave * 32 + m * 16 + i) * 64 + lane] = acc[m][i];
+    __syncthreads();
+    for (int e = tid; e < 32 * 64; e += 256) {
+        const int reg = e >> 6, ln = e & 63;
+        const float s = red[(0 * 32 + reg) * 64 + ln] + red[(1 * 32 + reg) * 64 + ln] + red[(2 * 32 + reg) * 64 + ln] + red[(3 * 32 + reg) * 64 + ln];
+        const int m = reg >> 4, i = reg & 15;
+        const int co = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5), k = ln & 31;
+        if (k < 27) atomicAdd(&dw[co * 27 + k], s);
+    }
+    if (dbias) {
+        __syncthreads();
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 64) atomicAdd(&dbias[tid], red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192]);
+    }
+}
+
 // data gradient wrt the NCHW fp32 image (D differentiated wrt G's output): one thread = one input pixel.
 template <typename T, int STRIDE, bool DY_NCHW>
 __global__ __launch_bounds__(256) void conv3x3_c3_dgrad_kernel(const void* __restrict__ dyv, int lddy, const void* __restrict__ yv, int ldy,
@@ -312,6 +417,14 @@ extern "C" int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     dim3 grid(grid_cap((long long)N * Ho * Wo, 64, 1024), cdiv(Cout, 64));
 #define C3W(T, ST, NCHW) hipLaunchKernelGGL((conv3x3_c3_wgrad_kernel<T, ST, NCHW>), grid, dim3(256), 0, s, x_nchw, dy, lddy, y, ldy_, act, dw_oihw, dbias, N, H, W, Cout)
+    if (!dy_nchw && dtype == WU_BF16 && Cout == 64 && ((uintptr_t)dy % 16) == 0 && (lddy % 8) == 0 && (!y || (((uintptr_t)y % 16) == 0 && (ldy_ % 8) == 0))) {
+        const long long ntiles = ((long long)N * Ho * Wo + 255) / 256;
+        const int g = (int)(ntiles < 1024 ? ntiles : 1024);
+        if (stride == 1) hipLaunchKernelGGL(conv3x3_c3_wgrad_mfma_kernel<1>, dim3(g), dim3(256), 0, s, x_nchw, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy_, act, dw_oihw, dbias, N, H, W);
+        else hipLaunchKernelGGL(conv3x3_c3_wgrad_mfma_kernel<2>, dim3(g), dim3(256), 0, s, x_nchw, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy_, act, dw_oihw, dbias, N, H, W);
+        WU_LAUNCH_CHECK("conv3x3_c3_wgrad_mfma");
+        return 0;
+    }
     if (dy_nchw) { if (stride == 1) C3W(float, 1, true); else C3W(float, 2, true); }
     else if (dtype == WU_BF16) { if (stride == 1) C3W(bf16_t, 1, false); else C3W(bf16_t, 2, false); }
     else { if (stride == 1) C3W(float, 1, false); else C3W(float, 2, false); }

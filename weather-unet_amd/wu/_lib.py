@@ -38,8 +38,8 @@ SIGNATURES = {
     "wu_maxpool2_fwd": (I, [P, I, P, I, I, I, I, I, I, P]),
     "wu_maxpool2_bwd": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, P]),
     "wu_adain_stats": (I, [P, I, P, P, I, I, I, I, F, I, P]),
-    "wu_adain_upcat_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, F, U64, I, P]),
-    "wu_adain_upcat_bwd": (I, [P, I, P, I, P, P, P, I, P, P, P, P, I, I, I, I, F, U64, I, P]),
+    "wu_adain_upcat_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, F, U64, P, I, P]),
+    "wu_adain_upcat_bwd": (I, [P, I, P, I, P, P, P, I, P, P, P, P, I, I, I, I, F, U64, P, I, P]),
     "wu_dropout_mask": (I, [P, I, I, I, I, F, U64, P]),
     "wu_sumpool_fwd": (I, [P, I, P, I, I, I, I, I, P]),
     "wu_sumpool_bwd": (I, [P, P, I, I, I, I, I, I, P]),

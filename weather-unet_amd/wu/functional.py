@@ -250,8 +250,13 @@ class AdaINUpCatFn(Function):
         ys = y_std.detach().float().contiguous()
         ym = y_mean.detach().float().contiguous()
         out = catbuf.detach()
+        mbits = None
+        if p_drop > 0 and ctx.needs_input_grad[0]:
+            mbits = torch.empty(n * 4 * h * w * (c * esz // 16), dtype=torch.uint8, device=x.device)
         _lib.call("wu_adain_upcat_fwd", x.data_ptr(), nhwc_ld(x), stats.data_ptr(), ys.data_ptr(), ym.data_ptr(),
-                  out.data_ptr(), ld, n, h, w, c, float(p_drop), int(seed), code, stream_ptr())
+                  out.data_ptr(), ld, n, h, w, c, float(p_drop), int(seed),
+                  mbits.data_ptr() if mbits is not None else None, code, stream_ptr())
+        ctx.mbits = mbits
         ctx.save_for_backward(x, stats, ys)
         ctx.meta = (code, float(p_drop), int(seed), cs)
         return out
@@ -269,7 +274,7 @@ class AdaINUpCatFn(Function):
         sums = torch.empty((n, c, 2 * (1 + MAX_SPLITS)), dtype=torch.float32, device=x.device)
         _lib.call("wu_adain_upcat_bwd", g.data_ptr(), nhwc_ld(g), x.data_ptr(), nhwc_ld(x), stats.data_ptr(), ys.data_ptr(),
                   dx.data_ptr(), nhwc_ld(dx), d_std.data_ptr(), d_mean.data_ptr(), gtmp.data_ptr(), sums.data_ptr(),
-                  n, h, w, c, p_drop, seed, code, stream_ptr())
+                  n, h, w, c, p_drop, seed, ctx.mbits.data_ptr() if ctx.mbits is not None else None, code, stream_ptr())
         dskip = g[:, c:] if ctx.needs_input_grad[3] else None     # a channel-slice view: no copy
         return dx, d_std, d_mean, dskip, None, None, None, None
 
