@@ -17,6 +17,7 @@
 // with (pixel >> 2) & 3 so a ds_read_b128 lane group touches 16 distinct slots (conflict-free for
 // TW = 32).  Same for the weight rows ([tap][cout] rows of 64 B).
 #include "wu_common.h"
+#include "conv_internal.h"
 
 #define WU_REP9(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8)
 
@@ -309,6 +310,15 @@ extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, cons
     hipStream_t s = (hipStream_t)stream;
     const bool m = mask != nullptr;
     const int fam = stride == 2 ? WU_FAM_CONV_S2 : (m ? WU_FAM_CONV_DGRAD : WU_FAM_CONV_FWD);
+    if (conv_v2_eligible(H, W, Cin, Cout, stride, dtype, m)) {
+        wu_prof_pre(fam, s);
+        const int rc = conv_v2_launch(x, ldx, w_packed, bias, y, ldy, N, H, W, Cin, Cout, act, s);
+        WU_REQUIRE(rc == 0, "conv3x3_fwd: grid too large");
+        wu_prof_post(fam, s, 2.0 * N * H * W * (double)Cout * 9.0 * Cin,
+                     ((double)N * H * W * (Cin + Cout) + 9.0 * Cin * Cout) * esz);
+        WU_LAUNCH_CHECK("conv3x3_mfma_v2");
+        return 0;
+    }
     wu_prof_pre(fam, s);
     if (dtype == WU_BF16) {
         if (stride == 1) { if (m) launch_conv<bf16_t, 1, true>(a, lds, (int)grid, s); else launch_conv<bf16_t, 1, false>(a, lds, (int)grid, s); }

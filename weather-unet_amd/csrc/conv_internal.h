@@ -1,0 +1,7 @@
+// internal: production conv3x3 path (conv3x3_mfma_v2.hip), dispatched from wu_conv3x3_fwd
+#pragma once
+#include <hip/hip_runtime.h>
+
+bool conv_v2_eligible(int H, int W, int Cin, int Cout, int stride, int dtype, bool masked);
+int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
+                   int N, int H, int W, int Cin, int Cout, int act, hipStream_t s);
