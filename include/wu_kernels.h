@@ -58,10 +58,14 @@ int wu_pack_conv3x3(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, i
  * If `mask` != NULL the staged input is gated by the activation derivative of `mask`
  * (same geometry as x, ld=ldmask):  x * (mask > 0 ? 1 : slope(mask_act)) -- this is how the
  * data-gradient pass (called with w_dgrad, Cin<->Cout swapped, stride 1) fuses the ReLU backward
- * of autograd (t_cls_train.py:272,307) into its input gather. */
+ * of autograd (t_cls_train.py:272,307) into its input gather.
+ * If `egate` != NULL the OUTPUT is multiplied by act'(egate) in the epilogue (egate: output geometry,
+ * ld=ldegate): used by the data-gradient pass to hand the upstream layer a gradient that is already gated
+ * by that layer's own activation (egate = this conv's forward input, which is that layer's output). */
 int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                    int N, int H, int W, int Cin, int Cout, int stride, int act,
-                   const void* mask, int ldmask, int mask_act, int dtype, void* stream);
+                   const void* mask, int ldmask, int mask_act,
+                   const void* egate, int ldegate, int egate_act, int dtype, void* stream);
 
 /* Weight + bias gradient of the conv above: dw_oihw[Cout][Cin][3][3] (+)= sum_pixels dy (x) x,
  * dbias[Cout] (+)= sum dy, with dy gated by act'(y) when `y` != NULL.  `workspace` must hold
@@ -75,10 +79,11 @@ int wu_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, const voi
 
 /* Data gradient of the stride-2 conv (nets.py:30-31): dx (N,H,W,Cin) from dy (N,Ho,Wo,Cout),
  * w_dgrad as packed above; dy gated by act'(y) when y != NULL.  `workspace` holds
- * wu_conv3x3_s2_dgrad_workspace() bytes (the zero-upsampled gradient). */
+ * wu_conv3x3_s2_dgrad_workspace() bytes (the zero-upsampled gradient); egate as in wu_conv3x3_fwd. */
 size_t wu_conv3x3_s2_dgrad_workspace(int N, int H, int W, int Cout, int dtype);
 int wu_conv3x3_s2_dgrad(const void* dy, int lddy, const void* y, int ldy_, int act, const void* w_dgrad,
                         void* dx, int lddx, void* workspace, size_t workspace_bytes,
+                        const void* egate, int ldegate, int egate_act,
                         int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
 
 /* Activation backward as one streaming pass: out = g * act'(y) (ReLU: y > 0; LeakyReLU: y > 0 ? 1 : 0.2),
@@ -109,19 +114,20 @@ int wu_conv3x3_c3_dgrad(const void* dy, int lddy, int dy_nchw, const void* y, in
  * x NHWC (N,H,W,Cin) ld=ldx, w (3,Cin) fp32. */
 int wu_conv1x1_tanh_fwd(const void* x, int ldx, const float* w, const float* bias, float* out_nchw,
                         int N, int H, int W, int Cin, int dtype, void* stream);
-/* backward: g = dout*(1-out^2); dx = W^T g (NHWC ld=lddx); dw (+)= g x^T; dbias (+)= sum g. */
+/* backward: g = dout*(1-out^2); dx = W^T g (NHWC ld=lddx) [* act'(x) if x_gate_act]; dw (+)= g x^T; dbias (+)= sum g. */
 int wu_conv1x1_tanh_bwd(const float* dout_nchw, const float* out_nchw, const void* x, int ldx, const float* w,
                         void* dx, int lddx, float* dw, float* dbias, int N, int H, int W, int Cin,
-                        int accumulate, int dtype, void* stream);
+                        int accumulate, int x_gate_act, int dtype, void* stream);
 
 /* ---- glue ------------------------------------------------------------------------------------
  * nn.MaxPool2d(2) (cunet.py:27; calls :46,49,52).  x (N,H,W,C) -> y (N,H/2,W/2,C). */
 int wu_maxpool2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, void* stream);
 /* dx = route(dy to the first arg-max of each window, PyTorch's tie rule) [+ dskip]:
  * `dskip` (may be NULL, ld=lddskip) is the gradient arriving over the skip connection of the same
- * tensor (cunet.py:62,69,76), summed here instead of by a separate autograd add. */
+ * tensor (cunet.py:62,69,76), summed here instead of by a separate autograd add.  gate_act != 0: the
+ * result is additionally multiplied by act'(x) (x is the pooled conv's activation output). */
 int wu_maxpool2_bwd(const void* x, int ldx, const void* dy, int lddy, const void* dskip, int lddskip,
-                    void* dx, int lddx, int N, int H, int W, int C, int dtype, void* stream);
+                    void* dx, int lddx, int N, int H, int W, int C, int gate_act, int dtype, void* stream);
 
 /* AdaIN instance statistics (utils.py:34-39,47): per (n,c) over H*W: stats[n][c] = {mean, rstd}
  * with rstd = 1/sqrt(unbiased_var + eps).  `scratch` holds N*C*2*WU_MAX_SPLITS floats (per-split partial
@@ -142,11 +148,12 @@ int wu_adain_upcat_fwd(const void* x, int ldx, const float* stats, const float* 
                        uint8_t* mask_bits, int dtype, void* stream);
 /* Backward of the above.  dy: gradient of the concat buffer channels [0,C) (N,2H,2W) ld=lddy.
  * Produces dx (N,H,W,C) ld=lddx and d_y_std, d_y_mean (N,C) fp32.  `gtmp` (N*H*W*C floats) and
- * `sums` (N*C*2*(1+WU_MAX_SPLITS) floats) are caller-provided scratch. */
+ * `sums` (N*C*2*(1+WU_MAX_SPLITS) floats) are caller-provided scratch.  x_gate_act != 0: dx is additionally multiplied by
+ * act'(x) (x is a conv activation output; the producer conv then receives a pre-gated gradient). */
 int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int ldx, const float* stats, const float* y_std,
                        void* dx, int lddx, float* d_y_std, float* d_y_mean, float* gtmp, float* sums,
                        int N, int H, int W, int C, float p_drop, uint64_t seed, const uint8_t* mask_bits,
-                       int dtype, void* stream);
+                       int x_gate_act, int dtype, void* stream);
 /* The keep-mask wu_adain_upcat_fwd draws for (seed, p): mask[n][c][h2][w2] (NCHW uint8), for tests. */
 int wu_dropout_mask(uint8_t* mask_nchw, int N, int H2, int W2, int C, float p_drop, uint64_t seed, void* stream);
 

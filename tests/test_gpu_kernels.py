@@ -145,10 +145,17 @@ def test_conv3x3_gated_abi_paths(p, act):
     assert (gg.float() - ref_gate).abs().max().item() <= (0 if p == "fp32" else 4e-3)
     dx = [empty_nhwc(n, cin, h, w, _tdt(p), _dev()) for _ in range(2)]
     _lib.call("wu_conv3x3_fwd", gy.data_ptr(), nhwc_ld(gy), w_dgrad.data_ptr(), None, dx[0].data_ptr(), cin, n, h, w, cout, cin, 1, 0,
-              y.data_ptr(), nhwc_ld(y), act, code, s)
+              y.data_ptr(), nhwc_ld(y), act, None, 0, 0, code, s)
     _lib.call("wu_conv3x3_fwd", gg.data_ptr(), nhwc_ld(gg), w_dgrad.data_ptr(), None, dx[1].data_ptr(), cin, n, h, w, cout, cin, 1, 0,
-              None, 0, 0, code, s)
+              None, 0, 0, None, 0, 0, code, s)
     assert torch.equal(dx[0], dx[1])
+    # epilogue gate: output * act'(egate) == act_gate(output, egate)
+    dxe = empty_nhwc(n, cin, h, w, _tdt(p), _dev())
+    _lib.call("wu_conv3x3_fwd", gg.data_ptr(), nhwc_ld(gg), w_dgrad.data_ptr(), None, dxe.data_ptr(), cin, n, h, w, cout, cin, 1, 0,
+              None, 0, 0, x.data_ptr(), nhwc_ld(x), act, code, s)
+    ref_e = empty_nhwc(n, cin, h, w, _tdt(p), _dev())
+    _lib.call("wu_act_gate", dx[1].data_ptr(), cin, x.data_ptr(), nhwc_ld(x), ref_e.data_ptr(), cin, n, h, w, cin, act, code, s)
+    assert torch.equal(dxe, ref_e)
     nbytes = _lib.load().wu_conv3x3_wgrad_workspace(n, h, w, cin, cout, 1, code)
     ws = WF.workspace(nbytes, _dev())
     dw = [torch.empty((cout, cin, 3, 3), device=_dev()) for _ in range(2)]
@@ -227,8 +234,13 @@ def test_maxpool_bwd_fused_skip(p):
     xd, gyd, gsd = _nhwc(x.detach(), p), _nhwc(gy, p), _nhwc(gs, p)
     dx = empty_nhwc(n, c, h, w, _tdt(p), _dev())
     _lib.call("wu_maxpool2_bwd", xd.data_ptr(), nhwc_ld(xd), gyd.data_ptr(), nhwc_ld(gyd), gsd.data_ptr(), nhwc_ld(gsd),
-              dx.data_ptr(), nhwc_ld(dx), n, h, w, c, precision_code(p), stream_ptr())
+              dx.data_ptr(), nhwc_ld(dx), n, h, w, c, 0, precision_code(p), stream_ptr())
     assert (dx.float().cpu() - want).abs().max().item() <= (1e-6 if p == "fp32" else 1.6e-2)
+    # ... and additionally gated by ReLU'(x) (the fused-graph form)
+    _lib.call("wu_maxpool2_bwd", xd.data_ptr(), nhwc_ld(xd), gyd.data_ptr(), nhwc_ld(gyd), gsd.data_ptr(), nhwc_ld(gsd),
+              dx.data_ptr(), nhwc_ld(dx), n, h, w, c, 1, precision_code(p), stream_ptr())
+    want_g = want * (x.detach() > 0)
+    assert (dx.float().cpu() - want_g).abs().max().item() <= (1e-6 if p == "fp32" else 1.6e-2)
 
 
 def _adain_upcat_ref(x, c_std, c_mean, skip, eps, mask):
@@ -308,7 +320,7 @@ def test_adain_upcat_bwd_mask_bits_vs_rehash(p):
         sums = torch.empty((n, c, 2 * (1 + WF.MAX_SPLITS)), device=_dev())
         _lib.call("wu_adain_upcat_bwd", g.data_ptr(), nhwc_ld(g), x.data_ptr(), nhwc_ld(x), stats.data_ptr(), ystd.data_ptr(),
                   dx.data_ptr(), nhwc_ld(dx), dstd.data_ptr(), dmean.data_ptr(), gtmp.data_ptr(), sums.data_ptr(),
-                  n, h, w, c, 0.3, seed, mb, code, s)
+                  n, h, w, c, 0.3, seed, mb, 0, code, s)
         res.append((dx.clone(), dstd.clone(), dmean.clone()))
     for a, b in zip(*res):
         assert torch.equal(a, b)

@@ -140,6 +140,30 @@ def test_cunet_stages_and_grads_vs_oracle(precision):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cunet_fused_graph_equals_per_layer_functions(precision):
+    """The single-node fused schedule (wu/unet_graph.py: epilogue-gated gradients, fused skip-sum) and the
+    per-layer autograd Functions are two schedules of the same kernels: same forward bits, same gradients up to the
+    one place they round differently (the encoder skip-gradient sum)."""
+    nc, seed = 5, 6
+    x, c = O.make_inputs(2, 64, nc, seed, True)
+    res = []
+    for fused in (True, False):
+        net = _make_g(nc, seed, precision).train()
+        net.dropout_seed = 7
+        net.fused = fused
+        xd = x.to(DEV)
+        out = net(xd, c.to(DEV))
+        torch.mean(torch.abs(out - xd)).backward()
+        res.append((out.detach(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    assert set(res[0][1]) == set(res[1][1]) and len(res[0][1]) == 36
+    for k in res[0][1]:
+        a, b = res[0][1][k].double().reshape(-1), res[1][1][k].double().reshape(-1)
+        rel = ((a - b).norm() / (b.norm() + 1e-30)).item()
+        assert rel <= (1e-5 if precision == "fp32" else 3e-2), f"{k}: {rel}"
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_cunet_train_mode_dropout(precision):
     """Train mode (Dropout(0.3) active, as in inf_transfer_c.py which never calls .eval()): the oracle is
     given the kernel's own keep-masks (regenerated from the seed through the C ABI)."""

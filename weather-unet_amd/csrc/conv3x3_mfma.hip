@@ -33,7 +33,8 @@ struct ConvArgs {
     const void* w;
     const float* bias;
     void* y;
-    int ldx, ldmask, ldy;
+    const void* egate;
+    int ldx, ldmask, ldy, ldegate, egate_act;
     int N, H, W, Ho, Wo, Cin, Cout;
     int act, mask_act;
     int tw_log2;      // tile width  = 1 << tw_log2  (output pixels)
@@ -252,7 +253,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
         const int r = q / kSlotsPerRow, s = q % kSlotsPerRow;
         const int oh = oh0 + (r >> a.tw_log2), ow = ow0 + (r & (TW - 1));
         if (oh < a.Ho && ow < a.Wo) {
-            const uint4 v = *(const uint4*)(smem + r * kRow + s * 16);
+            uint4 v = *(const uint4*)(smem + r * kRow + s * 16);
+            if (a.egate) {
+                const T* eg = (const T*)a.egate + ((size_t)n * a.Ho * a.Wo + (size_t)(oh * a.Wo + ow)) * a.ldegate + co0 + s * (16 / (int)sizeof(T));
+                v = gate16<T>(v, *(const uint4*)eg, a.egate_act);
+            }
             *(uint4*)(yout + (size_t)(oh * a.Wo + ow) * a.ldy + s * (16 / (int)sizeof(T))) = v;
         }
     }
@@ -275,7 +280,8 @@ int launch_conv(const ConvArgs& a, size_t lds_bytes, int grid, hipStream_t s) {
 
 extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                               int N, int H, int W, int Cin, int Cout, int stride, int act,
-                              const void* mask, int ldmask, int mask_act, int dtype, void* stream) {
+                              const void* mask, int ldmask, int mask_act,
+                              const void* egate, int ldegate, int egate_act, int dtype, void* stream) {
     const int esz = dtype == WU_BF16 ? 2 : 4;
     const int chunk = kChunkBytes / esz;
     WU_REQUIRE(dtype == WU_F32 || dtype == WU_BF16, "conv3x3_fwd: bad dtype %d", dtype);
@@ -288,9 +294,10 @@ extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, cons
     WU_REQUIRE((size_t)H * W * (size_t)(ldx > ldmask ? ldx : ldmask) < (1ull << 31), "conv3x3_fwd: image too large for 32-bit offsets");
     if (mask) WU_REQUIRE(stride == 1 && ldmask >= Cin && (ldmask * esz) % 16 == 0 && ((uintptr_t)mask % 16) == 0, "conv3x3_fwd: bad mask");
 
+    if (egate) WU_REQUIRE(((uintptr_t)egate % 16) == 0 && (ldegate * esz) % 16 == 0 && ldegate >= Cout, "conv3x3_fwd: bad egate");
     ConvArgs a;
-    a.x = x; a.mask = mask; a.w = w_packed; a.bias = bias; a.y = y;
-    a.ldx = ldx; a.ldmask = ldmask; a.ldy = ldy;
+    a.x = x; a.mask = mask; a.w = w_packed; a.bias = bias; a.y = y; a.egate = egate;
+    a.ldx = ldx; a.ldmask = ldmask; a.ldy = ldy; a.ldegate = ldegate; a.egate_act = egate_act;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
     a.act = act; a.mask_act = mask_act;
@@ -312,7 +319,7 @@ extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, cons
     const int fam = stride == 2 ? WU_FAM_CONV_S2 : (m ? WU_FAM_CONV_DGRAD : WU_FAM_CONV_FWD);
     if (conv_v2_eligible(H, W, Cin, Cout, stride, dtype, m)) {
         wu_prof_pre(fam, s);
-        const int rc = conv_v2_launch(x, ldx, w_packed, bias, y, ldy, N, H, W, Cin, Cout, act, s);
+        const int rc = conv_v2_launch(x, ldx, w_packed, bias, y, ldy, egate, ldegate, egate_act, N, H, W, Cin, Cout, act, s);
         WU_REQUIRE(rc == 0, "conv3x3_fwd: grid too large");
         wu_prof_post(fam, s, 2.0 * N * H * W * (double)Cout * 9.0 * Cin,
                      ((double)N * H * W * (Cin + Cout) + 9.0 * Cin * Cout) * esz);

@@ -32,8 +32,8 @@ struct K {
 };
 
 struct V2Args {
-    const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y;
-    int ldx, ldy;
+    const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; const bf16_t* egate;
+    int ldx, ldy, ldegate, egate_act;
     int N, H, W, Cin, Cout, act;
     int tiles_x, tiles_y, cout_tiles;
 };
@@ -190,7 +190,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a)
         const int r = q >> 3, s = q & 7;
         const int oh = oh0 + (r >> 5), ow = ow0 + (r & 31);
         if (oh < a.H && ow < a.W) {
-            const uint4 v = *(const uint4*)(smem + r * kRow + s * 16);
+            uint4 v = *(const uint4*)(smem + r * kRow + s * 16);
+            if (a.egate)
+                v = gate16<bf16_t>(v, *(const uint4*)(a.egate + ((size_t)n * a.H * a.W + (size_t)(oh * a.W + ow)) * a.ldegate + co0 + s * 8), a.egate_act);
             *(uint4*)(yout + (size_t)(oh * a.W + ow) * a.ldy + s * 8) = v;
         }
     }
@@ -204,10 +206,10 @@ bool conv_v2_eligible(int H, int W, int Cin, int Cout, int stride, int dtype, bo
 }
 
 int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
-                   int N, int H, int W, int Cin, int Cout, int act, hipStream_t s) {
+                   const void* egate, int ldegate, int egate_act, int N, int H, int W, int Cin, int Cout, int act, hipStream_t s) {
     V2Args a;
-    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y;
-    a.ldx = ldx; a.ldy = ldy; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.egate = (const bf16_t*)egate;
+    a.ldx = ldx; a.ldy = ldy; a.ldegate = ldegate; a.egate_act = egate_act; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act;
     a.tiles_x = cdiv(W, K::TW); a.tiles_y = cdiv(H, K::TH); a.cout_tiles = Cout / 64;
     const long long grid = (long long)N * a.tiles_x * a.tiles_y * a.cout_tiles;
     if (grid >= (1ll << 31)) return -1;

@@ -35,6 +35,7 @@ extern "C" size_t wu_conv3x3_s2_dgrad_workspace(int N, int H, int W, int Cout, i
 
 extern "C" int wu_conv3x3_s2_dgrad(const void* dy, int lddy, const void* y, int ldy_, int act, const void* w_dgrad,
                                    void* dx, int lddx, void* workspace, size_t workspace_bytes,
+                                   const void* egate, int ldegate, int egate_act,
                                    int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
     const int esz = dtype == WU_BF16 ? 2 : 4;
     WU_REQUIRE(Cout % (16 / esz) == 0 && ((uintptr_t)dy % 16) == 0 && (lddy * esz) % 16 == 0, "conv3x3_s2_dgrad: alignment");
@@ -52,5 +53,5 @@ extern "C" int wu_conv3x3_s2_dgrad(const void* dy, int lddy, const void* y, int 
     WU_LAUNCH_CHECK("conv3x3_s2_dgrad(upsample)");
     // stride-1 correlation of the upsampled gradient with the rotated filter: channels swap roles
     return wu_conv3x3_fwd(workspace, Cout, w_dgrad, nullptr, dx, lddx, N, H, W, /*Cin=*/Cout, /*Cout=*/Cin, 1, WU_ACT_NONE,
-                          nullptr, 0, 0, dtype, stream);
+                          nullptr, 0, 0, egate, ldegate, egate_act, dtype, stream);
 }

@@ -4,4 +4,4 @@
 
 bool conv_v2_eligible(int H, int W, int Cin, int Cout, int stride, int dtype, bool masked);
 int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
-                   int N, int H, int W, int Cin, int Cout, int act, hipStream_t s);
+                   const void* egate, int ldegate, int egate_act, int N, int H, int W, int Cin, int Cout, int act, hipStream_t s);

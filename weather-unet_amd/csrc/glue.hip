@@ -61,7 +61,7 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restr
 template <typename T>
 __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
                                     const T* __restrict__ dskip, int lddskip, T* __restrict__ dx, int lddx,
-                                    int N, int H, int W, int C) {
+                                    int N, int H, int W, int C, int gate_act) {
     constexpr int E = ElemTraits<T>::kPer16B;
     const int cpp = C / E, Ho = H / 2, Wo = W / 2;
     const long long total = (long long)N * Ho * Wo * cpp;
@@ -91,7 +91,7 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int ldx, const T* _
             float o[E];
             if (dskip) unpack16<T>(*(const uint4*)(dskip + (pix + offs[k]) * lddskip + ch * E), o);
 #pragma unroll
-            for (int e = 0; e < E; ++e) o[e] = (dskip ? o[e] : 0.f) + (arg[e] == k ? g[e] : 0.f);
+            for (int e = 0; e < E; ++e) o[e] = act_gate((dskip ? o[e] : 0.f) + (arg[e] == k ? g[e] : 0.f), v[k][e], gate_act);
             *(uint4*)(dx + (pix + offs[k]) * lddx + ch * E) = pack16<T>(o);
         }
     }
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_apply_kernel(const float*
                                              const T* __restrict__ x, int ldx, const float* __restrict__ stats,
                                              const float* __restrict__ y_std, T* __restrict__ dx, int lddx,
                                              float* __restrict__ d_y_std, float* __restrict__ d_y_mean,
-                                             int N, int HW, int C) {
+                                             int N, int HW, int C, int x_gate_act) {
     constexpr int E = ElemTraits<T>::kPer16B;
     const int cpp = C / E;
     const int n = blockIdx.y;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_apply_kernel(const float*
         for (int e = 0; e < E; ++e) {
             const float mean = st[2 * e], rstd = st[2 * e + 1], S1 = sm[2 * e], S2 = sm[2 * e + 1];
             const float xh = (xv[e] - mean) * rstd;
-            o[e] = ys[e] * rstd * (g[e] - S1 * inv_hw - xh * S2 * inv_hw1);
+            o[e] = act_gate(ys[e] * rstd * (g[e] - S1 * inv_hw - xh * S2 * inv_hw1), xv[e], x_gate_act);
             if (pix == 0) {
                 d_y_mean[sc + e] = S1;
                 d_y_std[sc + e] = S2;
@@ -550,13 +550,13 @@ extern "C" int wu_maxpool2_fwd(const void* x, int ldx, void* y, int ldy, int N, 
 }
 
 extern "C" int wu_maxpool2_bwd(const void* x, int ldx, const void* dy, int lddy, const void* dskip, int lddskip,
-                               void* dx, int lddx, int N, int H, int W, int C, int dtype, void* stream) {
+                               void* dx, int lddx, int N, int H, int W, int C, int gate_act, int dtype, void* stream) {
     const int esz = dtype == WU_BF16 ? 2 : 4;
     WU_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % (16 / esz) == 0, "maxpool2_bwd: bad shape");
     WU_REQUIRE(ok16(x, ldx, esz) && ok16(dy, lddy, esz) && ok16(dx, lddx, esz) && (!dskip || ok16(dskip, lddskip, esz)), "maxpool2_bwd: alignment");
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / (16 / esz));
     DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                                         (const T*)x, ldx, (const T*)dy, lddy, (const T*)dskip, lddskip, (T*)dx, lddx, N, H, W, C));
+                                         (const T*)x, ldx, (const T*)dy, lddy, (const T*)dskip, lddskip, (T*)dx, lddx, N, H, W, C, gate_act));
     WU_LAUNCH_CHECK("maxpool2_bwd");
     return 0;
 }
@@ -600,7 +600,7 @@ extern "C" int wu_adain_upcat_fwd(const void* x, int ldx, const float* stats, co
 extern "C" int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int ldx, const float* stats, const float* y_std,
                                   void* dx, int lddx, float* d_y_std, float* d_y_mean, float* gtmp, float* sums,
                                   int N, int H, int W, int C, float p_drop, uint64_t seed, const uint8_t* mask_bits,
-                                  int dtype, void* stream) {
+                                  int x_gate_act, int dtype, void* stream) {
     const int esz = dtype == WU_BF16 ? 2 : 4;
     WU_REQUIRE(C % 64 == 0 && H > 1 && W > 1, "adain_upcat_bwd: bad shape");
     WU_REQUIRE(((uintptr_t)stats % 16) == 0 && ((uintptr_t)sums % 16) == 0 && ((uintptr_t)y_std % 16) == 0, "adain_upcat_bwd: stats alignment");
@@ -620,7 +620,7 @@ extern "C" int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int l
                            stats, gtmp, partials, H, W, C, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), seed, mask_bits);
         hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(N * C * 2, 256)), dim3(256), 0, s, partials, sums, N * C * 2, splits);
         hipLaunchKernelGGL(adain_upcat_bwd_apply_kernel<T>, dim3(grid_for((long long)HW * (C / (16 / esz)), 256, 1024), N), dim3(256), 0, s, gtmp, sums, (const T*)x, ldx, stats, y_std,
-                           (T*)dx, lddx, d_y_std, d_y_mean, N, HW, C);
+                           (T*)dx, lddx, d_y_std, d_y_mean, N, HW, C, x_gate_act);
     });
     WU_LAUNCH_CHECK("adain_upcat_bwd");
     return 0;

@@ -329,7 +329,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv1x1_tanh_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                                const T* __restrict__ x, int ldx, const float* __restrict__ w,
                                                                T* __restrict__ dx, int lddx, float* __restrict__ dw, float* __restrict__ dbias,
-                                                               int N, int HW, int Cin) {
+                                                               int N, int HW, int Cin, int x_gate_act) {
     constexpr int E = ElemTraits<T>::kPer16B;
     __shared__ float red[3][65];      // [k][channel] + [k][64] = bias
     const int LP = Cin / E;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void conv1x1_tanh_bwd_kernel(const float* __re
         unpack16<T>(*(const uint4*)(x + (size_t)pix * ldx + cl * E), v);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            d[e] = g[0] * wr[0][e] + g[1] * wr[1][e] + g[2] * wr[2][e];
+            d[e] = act_gate(g[0] * wr[0][e] + g[1] * wr[1][e] + g[2] * wr[2][e], v[e], x_gate_act);
             aw[0][e] += g[0] * v[e]; aw[1][e] += g[1] * v[e]; aw[2][e] += g[2] * v[e];
         }
         if (cl == 0) { ab[0] += g[0]; ab[1] += g[1]; ab[2] += g[2]; }
@@ -466,7 +466,7 @@ extern "C" int wu_conv1x1_tanh_fwd(const void* x, int ldx, const float* w, const
 
 extern "C" int wu_conv1x1_tanh_bwd(const float* dout_nchw, const float* out_nchw, const void* x, int ldx, const float* w,
                                    void* dx, int lddx, float* dw, float* dbias, int N, int H, int W, int Cin,
-                                   int accumulate, int dtype, void* stream) {
+                                   int accumulate, int x_gate_act, int dtype, void* stream) {
     const int esz = dtype == WU_BF16 ? 2 : 4;
     const int E = 16 / esz;
     const int LP = Cin / E;
@@ -478,8 +478,8 @@ extern "C" int wu_conv1x1_tanh_bwd(const float* dout_nchw, const float* out_nchw
         hipMemsetAsync(dbias, 0, 3 * sizeof(float), s);
     }
     const int grid = grid_cap((long long)N * H * W, 256 / LP, 1024);
-    if (dtype == WU_BF16) hipLaunchKernelGGL(conv1x1_tanh_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, dout_nchw, out_nchw, (const bf16_t*)x, ldx, w, (bf16_t*)dx, lddx, dw, dbias, N, H * W, Cin);
-    else hipLaunchKernelGGL(conv1x1_tanh_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, dout_nchw, out_nchw, (const float*)x, ldx, w, (float*)dx, lddx, dw, dbias, N, H * W, Cin);
+    if (dtype == WU_BF16) hipLaunchKernelGGL(conv1x1_tanh_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, dout_nchw, out_nchw, (const bf16_t*)x, ldx, w, (bf16_t*)dx, lddx, dw, dbias, N, H * W, Cin, x_gate_act);
+    else hipLaunchKernelGGL(conv1x1_tanh_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, dout_nchw, out_nchw, (const float*)x, ldx, w, (float*)dx, lddx, dw, dbias, N, H * W, Cin, x_gate_act);
     WU_LAUNCH_CHECK("conv1x1_tanh_bwd");
     return 0;
 }

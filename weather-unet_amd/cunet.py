@@ -22,6 +22,7 @@ from nets import r_double_conv
 from utils import AdaIN, BatchNorm, HalfDropout  # noqa: F401  (names the reference imports, cunet.py:3)
 from wu import functional as WF
 from wu.layout import empty_nhwc, precision_code, require_cuda, torch_dtype
+from wu.unet_graph import unet_forward
 
 _SEED_COUNTER = itertools.count(1)
 
@@ -63,6 +64,7 @@ class Conditional_UNet(nn.Module):
         self.activation = nn.Tanh()
         self.set_precision(precision)
         self.dropout_seed = None     # int -> reproducible dropout masks (tests); None -> fresh seed per call
+        self.fused = True            # one autograd node for the whole net (wu/unet_graph.py); False = per-layer Functions
 
     def set_precision(self, precision):
         precision_code(precision)
@@ -92,6 +94,8 @@ class Conditional_UNet(nn.Module):
         n, _, h, w = x.shape
         if h % 8 or w % 8:
             raise ValueError(f"Conditional_UNet: H and W must be divisible by 8 (three 2x poolings), got {h}x{w}")
+        if self.fused:
+            return unet_forward(self, x, c)
         code = precision_code(self.precision)
         dt, dev = torch_dtype(code), x.device
         c = c.to(device=dev, dtype=torch.float32)

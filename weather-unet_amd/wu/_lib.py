@@ -24,22 +24,22 @@ SIGNATURES = {
     "wu_last_error": (c_char_p, []),
     "wu_version": (I, []),
     "wu_pack_conv3x3": (I, [P, P, P, I, I, P, I, P]),
-    "wu_conv3x3_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P, I, I, I, P]),
+    "wu_conv3x3_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P, I, I, P, I, I, I, P]),
     "wu_conv3x3_wgrad_workspace": (SZ, [I, I, I, I, I, I, I]),
     "wu_conv3x3_wgrad": (I, [P, I, P, I, P, I, I, P, P, P, SZ, I, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_s2_dgrad_workspace": (SZ, [I, I, I, I, I]),
-    "wu_conv3x3_s2_dgrad": (I, [P, I, P, I, I, P, P, I, P, SZ, I, I, I, I, I, I, P]),
+    "wu_conv3x3_s2_dgrad": (I, [P, I, P, I, I, P, P, I, P, SZ, P, I, I, I, I, I, I, I, I, P]),
     "wu_act_gate": (I, [P, I, P, I, P, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_c3_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_c3_wgrad": (I, [P, P, I, I, P, I, I, P, P, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_c3_dgrad": (I, [P, I, I, P, I, I, P, P, P, I, I, I, I, I, I, I, P]),
     "wu_conv1x1_tanh_fwd": (I, [P, I, P, P, P, I, I, I, I, I, P]),
-    "wu_conv1x1_tanh_bwd": (I, [P, P, P, I, P, P, I, P, P, I, I, I, I, I, I, P]),
+    "wu_conv1x1_tanh_bwd": (I, [P, P, P, I, P, P, I, P, P, I, I, I, I, I, I, I, P]),
     "wu_maxpool2_fwd": (I, [P, I, P, I, I, I, I, I, I, P]),
-    "wu_maxpool2_bwd": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, P]),
+    "wu_maxpool2_bwd": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I, P]),
     "wu_adain_stats": (I, [P, I, P, P, I, I, I, I, F, I, P]),
     "wu_adain_upcat_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, F, U64, P, I, P]),
-    "wu_adain_upcat_bwd": (I, [P, I, P, I, P, P, P, I, P, P, P, P, I, I, I, I, F, U64, P, I, P]),
+    "wu_adain_upcat_bwd": (I, [P, I, P, I, P, P, P, I, P, P, P, P, I, I, I, I, F, U64, P, I, I, P]),
     "wu_dropout_mask": (I, [P, I, I, I, I, F, U64, P]),
     "wu_sumpool_fwd": (I, [P, I, P, I, I, I, I, I, P]),
     "wu_sumpool_bwd": (I, [P, P, I, I, I, I, I, I, P]),

@@ -9,24 +9,11 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
+from . import kernels as K
+from .kernels import MAX_SPLITS, workspace  # noqa: F401  (re-exported: tests and callers size scratch with these)
 from .layout import (as_nhwc, dtype_code, empty_nhwc, nhwc_ld, require_cuda, stream_ptr, torch_dtype)
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = _lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_LEAKY
-MAX_SPLITS = 16     # WU_MAX_SPLITS of include/wu_kernels.h
-
-# ----------------------------------------------------------------------------------------------
-# workspaces (caller-owned, as the C ABI requires): one growable byte buffer per device
-# ----------------------------------------------------------------------------------------------
-_WS = {}
-
-
-def workspace(nbytes, device):
-    key = (device.type, device.index)
-    buf = _WS.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-        _WS[key] = buf
-    return buf
 
 
 def _grad_nhwc(g, code):
@@ -49,15 +36,7 @@ class PackedConv:
     def get(self, weight, code):
         key = (weight.data_ptr(), weight._version, code, tuple(weight.shape))
         if key != self.key:
-            cout, cin = weight.shape[:2]
-            tdt = torch_dtype(code)
-            w = weight.detach()
-            if not w.is_contiguous():
-                w = w.contiguous()
-            self.w_fwd = torch.empty((9, cout, cin), dtype=tdt, device=weight.device)
-            self.w_dgrad = torch.empty((9, cin, cout), dtype=tdt, device=weight.device)
-            _lib.call("wu_pack_conv3x3", w.data_ptr(), self.w_fwd.data_ptr(), self.w_dgrad.data_ptr(),
-                      cout, cin, None, code, stream_ptr())
+            self.w_fwd, self.w_dgrad = K.pack_conv3x3(weight, code)
             self.key = key
         return self.w_fwd, self.w_dgrad
 
@@ -79,9 +58,7 @@ class Conv3x3Fn(Function):
         else:
             assert tuple(out.shape) == (n, cout, ho, wo) and out.dtype == x.dtype
             y = out.detach()
-        _lib.call("wu_conv3x3_fwd", x.data_ptr(), nhwc_ld(x), w_fwd.data_ptr(),
-                  bias.data_ptr() if bias is not None else None, y.data_ptr(), nhwc_ld(y),
-                  n, h, w, cin, cout, stride, act, None, 0, 0, code, stream_ptr())
+        K.conv3x3(x, w_fwd, bias, y, stride, act)
         ctx.save_for_backward(x, y, w_dgrad)
         ctx.meta = (stride, act, code, tuple(weight.shape), bias is not None)
         return y
@@ -94,35 +71,22 @@ class Conv3x3Fn(Function):
         cout = wshape[0]
         ho, wo = y.shape[2], y.shape[3]
         gy = _grad_nhwc(gy, code)
-        s = stream_ptr()
         if act != ACT_NONE:
             # activation backward once, up front: both gradient GEMMs then read a pre-gated dY (the gated
             # in-kernel paths of the C ABI stay available: mask / y arguments)
-            gg = empty_nhwc(n, cout, ho, wo, y.dtype, y.device)
-            _lib.call("wu_act_gate", gy.data_ptr(), nhwc_ld(gy), y.data_ptr(), nhwc_ld(y), gg.data_ptr(), nhwc_ld(gg),
-                      n, ho, wo, cout, act, code, s)
-            gy = gg
+            gy = K.act_gate(gy, y, act)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = empty_nhwc(n, cin, h, w, x.dtype, x.device)
             if stride == 1:
-                _lib.call("wu_conv3x3_fwd", gy.data_ptr(), nhwc_ld(gy), w_dgrad.data_ptr(), None, dx.data_ptr(), nhwc_ld(dx),
-                          n, h, w, cout, cin, 1, ACT_NONE, None, 0, 0, code, s)
+                K.conv3x3(gy, w_dgrad, None, dx)
             else:
-                nbytes = _lib.load().wu_conv3x3_s2_dgrad_workspace(n, h, w, cout, code)
-                ws = workspace(nbytes, x.device)
-                _lib.call("wu_conv3x3_s2_dgrad", gy.data_ptr(), nhwc_ld(gy), None, 0, ACT_NONE,
-                          w_dgrad.data_ptr(), dx.data_ptr(), nhwc_ld(dx), ws.data_ptr(), ws.numel(),
-                          n, h, w, cin, cout, code, s)
+                K.conv3x3_s2_dgrad(gy, w_dgrad, dx)
         dw = db = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
             db = torch.empty((cout,), dtype=torch.float32, device=x.device) if has_bias else None
-            nbytes = _lib.load().wu_conv3x3_wgrad_workspace(n, h, w, cin, cout, stride, code)
-            ws = workspace(nbytes, x.device)
-            _lib.call("wu_conv3x3_wgrad", x.data_ptr(), nhwc_ld(x), gy.data_ptr(), nhwc_ld(gy), None, 0, ACT_NONE,
-                      dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
-                      n, h, w, cin, cout, stride, 0, code, s)
+            K.conv3x3_wgrad(x, gy, dw, db, stride)
         return dx, dw, db, None, None, None, None
 
 
@@ -146,12 +110,9 @@ class ConvC3Fn(Function):
         wt = weight.detach().contiguous()
         if out_nchw:
             y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
-            ldy = 0
         else:
             y = empty_nhwc(n, cout, ho, wo, torch_dtype(code), x.device)
-            ldy = cout
-        _lib.call("wu_conv3x3_c3_fwd", x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None, None,
-                  y.data_ptr(), ldy, 1 if out_nchw else 0, n, h, w, cout, stride, act, code, stream_ptr())
+        K.conv3x3_c3(x, wt, bias, y, stride, act, out_nchw, code)
         ctx.save_for_backward(x, y, wt)
         ctx.meta = (stride, act, code, out_nchw, bias is not None)
         return y
@@ -162,23 +123,15 @@ class ConvC3Fn(Function):
         stride, act, code, out_nchw, has_bias = ctx.meta
         n, _, h, w = x.shape
         cout = wt.shape[0]
-        s = stream_ptr()
-        if out_nchw:
-            gy = gy.float().contiguous()
-            ldg = ldy = 0
-        else:
-            gy = _grad_nhwc(gy, code)
-            ldg, ldy = nhwc_ld(gy), nhwc_ld(y)
-        gate = y.data_ptr() if act != ACT_NONE else None
+        gy = gy.float().contiguous() if out_nchw else _grad_nhwc(gy, code)
+        gate = y if act != ACT_NONE else None
         dw = torch.empty(wt.shape, dtype=torch.float32, device=x.device)
         db = torch.empty((cout,), dtype=torch.float32, device=x.device) if has_bias else None
-        _lib.call("wu_conv3x3_c3_wgrad", x.data_ptr(), gy.data_ptr(), ldg, 1 if out_nchw else 0, gate, ldy, act,
-                  dw.data_ptr(), db.data_ptr() if db is not None else None, n, h, w, cout, stride, 0, code, s)
+        K.conv3x3_c3_wgrad(x, gy, dw, db, stride, code, dy_nchw=out_nchw, y=gate, act=act)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.call("wu_conv3x3_c3_dgrad", gy.data_ptr(), ldg, 1 if out_nchw else 0, gate, ldy, act,
-                      wt.data_ptr(), None, dx.data_ptr(), n, h, w, cout, stride, 0, code, s)
+            K.conv3x3_c3_dgrad(gy, wt, dx, stride, code, dy_nchw=out_nchw, y=gate, act=act)
         return dx, dw, db, None, None, None, None
 
 
@@ -198,7 +151,7 @@ class MaxPool2Fn(Function):
         if h % 2 or w % 2:
             raise ValueError(f"maxpool2: H and W must be even, got {h}x{w}")
         y = empty_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
-        _lib.call("wu_maxpool2_fwd", x.data_ptr(), nhwc_ld(x), y.data_ptr(), nhwc_ld(y), n, h, w, c, code, stream_ptr())
+        K.maxpool2(x, y)
         ctx.save_for_backward(x)
         return y
 
@@ -209,8 +162,7 @@ class MaxPool2Fn(Function):
         n, c, h, w = x.shape
         gy = _grad_nhwc(gy, code)
         dx = empty_nhwc(n, c, h, w, x.dtype, x.device)
-        _lib.call("wu_maxpool2_bwd", x.data_ptr(), nhwc_ld(x), gy.data_ptr(), nhwc_ld(gy), None, 0,
-                  dx.data_ptr(), nhwc_ld(dx), n, h, w, c, code, stream_ptr())
+        K.maxpool2_bwd(x, gy, dx)
         return dx
 
 
@@ -223,12 +175,7 @@ def maxpool2(x):
 # ----------------------------------------------------------------------------------------------
 def adain_stats(x, eps):
     """{mean, rstd} per (n, c): (N, C, 2) fp32."""
-    code = dtype_code(x)
-    n, c, h, w = x.shape
-    stats = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
-    scratch = torch.empty((n, c, 2 * MAX_SPLITS), dtype=torch.float32, device=x.device)
-    _lib.call("wu_adain_stats", x.data_ptr(), nhwc_ld(x), stats.data_ptr(), scratch.data_ptr(), n, h, w, c, float(eps), code, stream_ptr())
-    return stats
+    return K.adain_stats(x, eps)
 
 
 class AdaINUpCatFn(Function):
@@ -250,13 +197,7 @@ class AdaINUpCatFn(Function):
         ys = y_std.detach().float().contiguous()
         ym = y_mean.detach().float().contiguous()
         out = catbuf.detach()
-        mbits = None
-        if p_drop > 0 and ctx.needs_input_grad[0]:
-            mbits = torch.empty(n * 4 * h * w * (c * esz // 16), dtype=torch.uint8, device=x.device)
-        _lib.call("wu_adain_upcat_fwd", x.data_ptr(), nhwc_ld(x), stats.data_ptr(), ys.data_ptr(), ym.data_ptr(),
-                  out.data_ptr(), ld, n, h, w, c, float(p_drop), int(seed),
-                  mbits.data_ptr() if mbits is not None else None, code, stream_ptr())
-        ctx.mbits = mbits
+        ctx.mbits = K.adain_upcat(x, stats, ys, ym, out, p_drop, seed, ctx.needs_input_grad[0])
         ctx.save_for_backward(x, stats, ys)
         ctx.meta = (code, float(p_drop), int(seed), cs)
         return out
@@ -268,13 +209,7 @@ class AdaINUpCatFn(Function):
         n, c, h, w = x.shape
         g = _grad_nhwc(g, code)
         dx = empty_nhwc(n, c, h, w, x.dtype, x.device)
-        d_std = torch.empty((n, c), dtype=torch.float32, device=x.device)
-        d_mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
-        gtmp = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
-        sums = torch.empty((n, c, 2 * (1 + MAX_SPLITS)), dtype=torch.float32, device=x.device)
-        _lib.call("wu_adain_upcat_bwd", g.data_ptr(), nhwc_ld(g), x.data_ptr(), nhwc_ld(x), stats.data_ptr(), ys.data_ptr(),
-                  dx.data_ptr(), nhwc_ld(dx), d_std.data_ptr(), d_mean.data_ptr(), gtmp.data_ptr(), sums.data_ptr(),
-                  n, h, w, c, p_drop, seed, ctx.mbits.data_ptr() if ctx.mbits is not None else None, code, stream_ptr())
+        d_std, d_mean = K.adain_upcat_bwd(g, x, stats, ys, dx, p_drop, seed, ctx.mbits)
         dskip = g[:, c:] if ctx.needs_input_grad[3] else None     # a channel-slice view: no copy
         return dx, d_std, d_mean, dskip, None, None, None, None
 
@@ -302,8 +237,7 @@ class Conv1x1TanhFn(Function):
         n, cin, h, w = x.shape
         wt = weight.detach().reshape(3, cin).contiguous()
         out = torch.empty((n, 3, h, w), dtype=torch.float32, device=x.device)
-        _lib.call("wu_conv1x1_tanh_fwd", x.data_ptr(), nhwc_ld(x), wt.data_ptr(), bias.data_ptr(), out.data_ptr(),
-                  n, h, w, cin, code, stream_ptr())
+        K.conv1x1_tanh(x, wt, bias, out)
         ctx.save_for_backward(x, wt, out)
         ctx.wshape = tuple(weight.shape)
         return out
@@ -317,8 +251,7 @@ class Conv1x1TanhFn(Function):
         dx = empty_nhwc(n, cin, h, w, x.dtype, x.device)
         dw = torch.empty((3, cin), dtype=torch.float32, device=x.device)
         db = torch.empty((3,), dtype=torch.float32, device=x.device)
-        _lib.call("wu_conv1x1_tanh_bwd", gout.data_ptr(), out.data_ptr(), x.data_ptr(), nhwc_ld(x), wt.data_ptr(),
-                  dx.data_ptr(), nhwc_ld(dx), dw.data_ptr(), db.data_ptr(), n, h, w, cin, 0, code, stream_ptr())
+        K.conv1x1_tanh_bwd(gout, out, x, wt, dx, dw, db)
         return dx, dw.view(ctx.wshape), db
 
 

@@ -1,0 +1,188 @@
+"""Typed launch helpers over the C ABI (include/wu_kernels.h): tensors in, one ``_lib.call`` out.
+
+Every helper takes NHWC-strided tensors (logical NCHW shape, see ``layout``), passes (pointer, pixel stride)
+pairs through ctypes and enqueues on torch's current HIP stream.  Nothing here allocates except the
+explicitly named workspaces; nothing here falls back to torch arithmetic.
+"""
+import torch
+
+from . import _lib
+from .layout import dtype_code, empty_nhwc, nhwc_ld, stream_ptr
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = _lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_LEAKY
+MAX_SPLITS = 16     # WU_MAX_SPLITS
+
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """One growable caller-owned byte buffer per device (the C ABI never allocates)."""
+    key = (device.type, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _pl(t):
+    """(pointer, ld) of an optional NHWC tensor."""
+    return (t.data_ptr(), nhwc_ld(t)) if t is not None else (None, 0)
+
+
+def conv3x3(x, w_packed, bias, y, stride=1, act=ACT_NONE, mask=None, mask_act=ACT_NONE, egate=None, egate_act=ACT_NONE):
+    """y = act(conv3x3(x [gated by mask]) + bias) [* act'(egate)]  -- wu_conv3x3_fwd."""
+    n, cin, h, w = x.shape
+    cout = y.shape[1]
+    mp, mld = _pl(mask)
+    ep, eld = _pl(egate)
+    _lib.call("wu_conv3x3_fwd", x.data_ptr(), nhwc_ld(x), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+              y.data_ptr(), nhwc_ld(y), n, h, w, cin, cout, stride, act, mp, mld, mask_act, ep, eld, egate_act,
+              dtype_code(x), stream_ptr())
+    return y
+
+
+def conv3x3_s2_dgrad(gy, w_dgrad, dx, y=None, act=ACT_NONE, egate=None, egate_act=ACT_NONE):
+    n, cin, h, w = dx.shape
+    cout = gy.shape[1]
+    code = dtype_code(gy)
+    nbytes = _lib.load().wu_conv3x3_s2_dgrad_workspace(n, h, w, cout, code)
+    ws = workspace(nbytes, gy.device)
+    yp, yld = _pl(y)
+    ep, eld = _pl(egate)
+    _lib.call("wu_conv3x3_s2_dgrad", gy.data_ptr(), nhwc_ld(gy), yp, yld, act, w_dgrad.data_ptr(), dx.data_ptr(), nhwc_ld(dx),
+              ws.data_ptr(), ws.numel(), ep, eld, egate_act, n, h, w, cin, cout, code, stream_ptr())
+    return dx
+
+
+def conv3x3_wgrad(x, gy, dw, db, stride=1, y=None, act=ACT_NONE, accumulate=False):
+    """dw (OIHW fp32) / db from x and the (pre-gated unless y is given) output gradient gy."""
+    n, cin, h, w = x.shape
+    cout = gy.shape[1]
+    code = dtype_code(x)
+    nbytes = _lib.load().wu_conv3x3_wgrad_workspace(n, h, w, cin, cout, stride, code)
+    ws = workspace(nbytes, x.device)
+    yp, yld = _pl(y)
+    _lib.call("wu_conv3x3_wgrad", x.data_ptr(), nhwc_ld(x), gy.data_ptr(), nhwc_ld(gy), yp, yld, act,
+              dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
+              n, h, w, cin, cout, stride, 1 if accumulate else 0, code, stream_ptr())
+
+
+def act_gate(g, y, act, out=None):
+    n, c, h, w = g.shape
+    if out is None:
+        out = empty_nhwc(n, c, h, w, g.dtype, g.device)
+    _lib.call("wu_act_gate", g.data_ptr(), nhwc_ld(g), y.data_ptr(), nhwc_ld(y), out.data_ptr(), nhwc_ld(out),
+              n, h, w, c, act, dtype_code(g), stream_ptr())
+    return out
+
+
+def conv3x3_c3(x_nchw, weight, bias, y, stride, act, out_nchw, code):
+    n, _, h, w = x_nchw.shape
+    cout = weight.shape[0]
+    _lib.call("wu_conv3x3_c3_fwd", x_nchw.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, None,
+              y.data_ptr(), 0 if out_nchw else nhwc_ld(y), 1 if out_nchw else 0, n, h, w, cout, stride, act, code, stream_ptr())
+    return y
+
+
+def conv3x3_c3_wgrad(x_nchw, gy, dw, db, stride, code, dy_nchw=False, y=None, act=ACT_NONE, accumulate=False):
+    n, _, h, w = x_nchw.shape
+    cout = dw.shape[0]
+    if dy_nchw:
+        ldg, yp, yld = 0, (y.data_ptr() if y is not None else None), 0
+    else:
+        ldg = nhwc_ld(gy)
+        yp, yld = _pl(y)
+    _lib.call("wu_conv3x3_c3_wgrad", x_nchw.data_ptr(), gy.data_ptr(), ldg, 1 if dy_nchw else 0, yp, yld, act,
+              dw.data_ptr(), db.data_ptr() if db is not None else None, n, h, w, cout, stride, 1 if accumulate else 0, code, stream_ptr())
+
+
+def conv3x3_c3_dgrad(gy, weight, dx_nchw, stride, code, dy_nchw=False, y=None, act=ACT_NONE, accumulate=False):
+    n, _, h, w = dx_nchw.shape
+    cout = weight.shape[0]
+    if dy_nchw:
+        ldg, yp, yld = 0, (y.data_ptr() if y is not None else None), 0
+    else:
+        ldg = nhwc_ld(gy)
+        yp, yld = _pl(y)
+    _lib.call("wu_conv3x3_c3_dgrad", gy.data_ptr(), ldg, 1 if dy_nchw else 0, yp, yld, act, weight.data_ptr(), None,
+              dx_nchw.data_ptr(), n, h, w, cout, stride, 1 if accumulate else 0, code, stream_ptr())
+
+
+def maxpool2(x, y):
+    n, c, h, w = x.shape
+    _lib.call("wu_maxpool2_fwd", x.data_ptr(), nhwc_ld(x), y.data_ptr(), nhwc_ld(y), n, h, w, c, dtype_code(x), stream_ptr())
+    return y
+
+
+def maxpool2_bwd(x, gy, dx, dskip=None, gate_act=ACT_NONE):
+    n, c, h, w = x.shape
+    sp, sld = _pl(dskip)
+    _lib.call("wu_maxpool2_bwd", x.data_ptr(), nhwc_ld(x), gy.data_ptr(), nhwc_ld(gy), sp, sld, dx.data_ptr(), nhwc_ld(dx),
+              n, h, w, c, gate_act, dtype_code(x), stream_ptr())
+    return dx
+
+
+def adain_stats(x, eps):
+    """{mean, rstd} per (n, c): (N, C, 2) fp32 (utils.py:34-39,47)."""
+    n, c, h, w = x.shape
+    stats = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+    scratch = torch.empty((n, c, 2 * MAX_SPLITS), dtype=torch.float32, device=x.device)
+    _lib.call("wu_adain_stats", x.data_ptr(), nhwc_ld(x), stats.data_ptr(), scratch.data_ptr(), n, h, w, c, float(eps),
+              dtype_code(x), stream_ptr())
+    return stats
+
+
+def adain_upcat(x, stats, y_std, y_mean, cat, p_drop, seed, want_mask_bits):
+    """Writes channels [0, C) of `cat`; returns the keep-bit tensor (or None)."""
+    n, c, h, w = x.shape
+    esz = x.element_size()
+    mbits = None
+    if p_drop > 0 and want_mask_bits:
+        mbits = torch.empty(n * 4 * h * w * (c * esz // 16), dtype=torch.uint8, device=x.device)
+    _lib.call("wu_adain_upcat_fwd", x.data_ptr(), nhwc_ld(x), stats.data_ptr(), y_std.data_ptr(), y_mean.data_ptr(),
+              cat.data_ptr(), nhwc_ld(cat), n, h, w, c, float(p_drop), int(seed),
+              mbits.data_ptr() if mbits is not None else None, dtype_code(x), stream_ptr())
+    return mbits
+
+
+def adain_upcat_bwd(g_cat, x, stats, y_std, dx, p_drop, seed, mbits, x_gate_act=ACT_NONE):
+    """Returns (d_y_std, d_y_mean); dx is written (optionally gated by act'(x))."""
+    n, c, h, w = x.shape
+    d_std = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    d_mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    gtmp = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    sums = torch.empty((n, c, 2 * (1 + MAX_SPLITS)), dtype=torch.float32, device=x.device)
+    _lib.call("wu_adain_upcat_bwd", g_cat.data_ptr(), nhwc_ld(g_cat), x.data_ptr(), nhwc_ld(x), stats.data_ptr(), y_std.data_ptr(),
+              dx.data_ptr(), nhwc_ld(dx), d_std.data_ptr(), d_mean.data_ptr(), gtmp.data_ptr(), sums.data_ptr(),
+              n, h, w, c, float(p_drop), int(seed), mbits.data_ptr() if mbits is not None else None, x_gate_act,
+              dtype_code(x), stream_ptr())
+    return d_std, d_mean
+
+
+def conv1x1_tanh(x, w3c, bias, out_nchw):
+    n, cin, h, w = x.shape
+    _lib.call("wu_conv1x1_tanh_fwd", x.data_ptr(), nhwc_ld(x), w3c.data_ptr(), bias.data_ptr(), out_nchw.data_ptr(),
+              n, h, w, cin, dtype_code(x), stream_ptr())
+    return out_nchw
+
+
+def conv1x1_tanh_bwd(gout, out, x, w3c, dx, dw, db, x_gate_act=ACT_NONE, accumulate=False):
+    n, cin, h, w = x.shape
+    _lib.call("wu_conv1x1_tanh_bwd", gout.data_ptr(), out.data_ptr(), x.data_ptr(), nhwc_ld(x), w3c.data_ptr(),
+              dx.data_ptr(), nhwc_ld(dx), dw.data_ptr(), db.data_ptr(), n, h, w, cin, 1 if accumulate else 0, x_gate_act,
+              dtype_code(x), stream_ptr())
+
+
+def pack_conv3x3(weight, code):
+    """(w_fwd [9][Cout][Cin], w_dgrad [9][Cin][Cout]) in the compute dtype."""
+    from .layout import torch_dtype
+    cout, cin = weight.shape[:2]
+    tdt = torch_dtype(code)
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    w_fwd = torch.empty((9, cout, cin), dtype=tdt, device=weight.device)
+    w_dgrad = torch.empty((9, cin, cout), dtype=tdt, device=weight.device)
+    _lib.call("wu_pack_conv3x3", w.data_ptr(), w_fwd.data_ptr(), w_dgrad.data_ptr(), cout, cin, None, code, stream_ptr())
+    return w_fwd, w_dgrad

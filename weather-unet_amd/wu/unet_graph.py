@@ -1,0 +1,186 @@
+"""The whole Conditional_UNet forward / backward (reference cunet.py:43-82 + autograd) as ONE autograd node
+with a static kernel schedule.
+
+Why a single node instead of one autograd.Function per layer (``wu.functional``, still used when the blocks
+are called on their own): inside the network every producer / consumer pair is ours, so the schedule can
+  * hand each conv a PRE-GATED output gradient -- the ReLU backward of layer L is applied in the epilogue of
+    whichever kernel produces dL/d(out_L) (the next conv's data-gradient pass, the fused max-pool backward, the
+    AdaIN/upsample backward, the 1x1 head backward), so no stand-alone activation-backward pass runs and both
+    gradient GEMMs stage their operands with plain LDS-DMA;
+  * sum the two gradients of every encoder skip tensor (max-pool path + concat path, cunet.py:46,62) inside
+    the max-pool backward kernel instead of a separate elementwise add;
+  * reuse the zero-copy concat buffers and never touch autograd's per-op bookkeeping (45 ops -> 1 node).
+"""
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+from .layout import empty_nhwc, precision_code, torch_dtype
+
+RELU = K.ACT_RELU
+BLOCKS = ("dconv_down1", "dconv_down2", "dconv_down3", "dconv_down4", "dconv_up3", "dconv_up2", "dconv_up1")
+
+
+def _new(n, c, h, w, dt, dev):
+    return empty_nhwc(n, c, h, w, dt, dev)
+
+
+class UNetFn(Function):
+    @staticmethod
+    def forward(ctx, meta, x, ys3, ym3, ys2, ym2, ys1, ym1, *params):
+        code, p_drop, seeds, eps, packed = meta
+        dt, dev = torch_dtype(code), x.device
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        n, _, h, w = x.shape
+        P = list(params)
+        wb = {name: (P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]) for i, name in enumerate(BLOCKS)}
+        w_last, b_last = P[28], P[29]
+        pk = {}                                  # (w_fwd, w_dgrad) per MFMA conv
+        for i, name in enumerate(BLOCKS):
+            w0, _, w2, _ = wb[name]
+            if name != "dconv_down1":
+                pk[name + ".0"] = packed[2 * i].get(w0, code)
+            pk[name + ".2"] = packed[2 * i + 1].get(w2, code)
+        want_bits = any(ctx.needs_input_grad)
+
+        cat1 = _new(n, 192, h, w, dt, dev)
+        cat2 = _new(n, 384, h // 2, w // 2, dt, dev)
+        cat3 = _new(n, 768, h // 4, w // 4, dt, dev)
+        conv1, conv2, conv3 = cat1[:, 128:], cat2[:, 256:], cat3[:, 512:]
+
+        # ---- encoder (cunet.py:45-54) ----
+        a1 = K.conv3x3_c3(x, wb["dconv_down1"][0].detach().contiguous(), wb["dconv_down1"][1], _new(n, 64, h, w, dt, dev), 1, RELU, False, code)
+        K.conv3x3(a1, pk["dconv_down1.2"][0], wb["dconv_down1"][3], conv1, 1, RELU)
+        p1 = K.maxpool2(conv1, _new(n, 64, h // 2, w // 2, dt, dev))
+        a2 = K.conv3x3(p1, pk["dconv_down2.0"][0], wb["dconv_down2"][1], _new(n, 128, h // 2, w // 2, dt, dev), 1, RELU)
+        K.conv3x3(a2, pk["dconv_down2.2"][0], wb["dconv_down2"][3], conv2, 1, RELU)
+        p2 = K.maxpool2(conv2, _new(n, 128, h // 4, w // 4, dt, dev))
+        a3 = K.conv3x3(p2, pk["dconv_down3.0"][0], wb["dconv_down3"][1], _new(n, 256, h // 4, w // 4, dt, dev), 1, RELU)
+        K.conv3x3(a3, pk["dconv_down3.2"][0], wb["dconv_down3"][3], conv3, 1, RELU)
+        p3 = K.maxpool2(conv3, _new(n, 256, h // 8, w // 8, dt, dev))
+        a4 = K.conv3x3(p3, pk["dconv_down4.0"][0], wb["dconv_down4"][1], _new(n, 512, h // 8, w // 8, dt, dev), 1, RELU)
+        b4 = K.conv3x3(a4, pk["dconv_down4.2"][0], wb["dconv_down4"][3], _new(n, 512, h // 8, w // 8, dt, dev), 1, RELU)
+
+        # ---- decoder (cunet.py:59-78): adain -> upsample -> dropout -> cat fused, then r_double_conv ----
+        ys = [t.detach().float().contiguous() for t in (ys3, ys2, ys1)]
+        ym = [t.detach().float().contiguous() for t in (ym3, ym2, ym1)]
+        st3 = K.adain_stats(b4, eps)
+        mb3 = K.adain_upcat(b4, st3, ys[0], ym[0], cat3, p_drop, seeds[0], want_bits)
+        u3a = K.conv3x3(cat3, pk["dconv_up3.0"][0], wb["dconv_up3"][1], _new(n, 256, h // 4, w // 4, dt, dev), 1, RELU)
+        u3b = K.conv3x3(u3a, pk["dconv_up3.2"][0], wb["dconv_up3"][3], _new(n, 256, h // 4, w // 4, dt, dev), 1, RELU)
+        st2 = K.adain_stats(u3b, eps)
+        mb2 = K.adain_upcat(u3b, st2, ys[1], ym[1], cat2, p_drop, seeds[1], want_bits)
+        u2a = K.conv3x3(cat2, pk["dconv_up2.0"][0], wb["dconv_up2"][1], _new(n, 128, h // 2, w // 2, dt, dev), 1, RELU)
+        u2b = K.conv3x3(u2a, pk["dconv_up2.2"][0], wb["dconv_up2"][3], _new(n, 128, h // 2, w // 2, dt, dev), 1, RELU)
+        st1 = K.adain_stats(u2b, eps)
+        mb1 = K.adain_upcat(u2b, st1, ys[2], ym[2], cat1, p_drop, seeds[2], want_bits)
+        u1a = K.conv3x3(cat1, pk["dconv_up1.0"][0], wb["dconv_up1"][1], _new(n, 64, h, w, dt, dev), 1, RELU)
+        u1b = K.conv3x3(u1a, pk["dconv_up1.2"][0], wb["dconv_up1"][3], _new(n, 64, h, w, dt, dev), 1, RELU)
+
+        # ---- head (cunet.py:80-82) ----
+        w3c = w_last.detach().reshape(3, 64).contiguous()
+        out = K.conv1x1_tanh(u1b, w3c, b_last, torch.empty((n, 3, h, w), dtype=torch.float32, device=dev))
+
+        if want_bits:
+            ctx.save_for_backward(x, a1, cat1, p1, a2, cat2, p2, a3, cat3, p3, a4, b4, u3a, u3b, u2a, u2b, u1a, u1b, out,
+                                  st3, st2, st1, ys[0], ys[1], ys[2], w3c, wb["dconv_down1"][0].detach())
+            ctx.pk_dgrad = {k: v[1] for k, v in pk.items()}
+            ctx.mbits = (mb3, mb2, mb1)
+            ctx.meta = (code, p_drop, seeds, [tuple(p.shape) for p in P])
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (x, a1, cat1, p1, a2, cat2, p2, a3, cat3, p3, a4, b4, u3a, u3b, u2a, u2b, u1a, u1b, out,
+         st3, st2, st1, ys3, ys2, ys1, w3c, w_first) = ctx.saved_tensors
+        code, p_drop, seeds, shapes = ctx.meta
+        wd = ctx.pk_dgrad
+        mb3, mb2, mb1 = ctx.mbits
+        dev, dt = x.device, u1b.dtype
+        n, _, h, w = x.shape
+        f32 = dict(dtype=torch.float32, device=dev)
+        grads = {}
+
+        def wgrad(name, j, xin, gy):
+            dw = torch.empty(shapes[4 * BLOCKS.index(name) + j], **f32)
+            db = torch.empty(shapes[4 * BLOCKS.index(name) + j + 1], **f32)
+            K.conv3x3_wgrad(xin, gy, dw, db)
+            grads[(name, j)] = (dw, db)
+
+        def block_bwd(name, xin, mid, g_out_gated, need_dx=True):
+            """r_double_conv backward given the PRE-GATED gradient of its output; returns dL/d(xin) (ungated)."""
+            wgrad(name, 2, mid, g_out_gated)
+            g_mid = K.conv3x3(g_out_gated, wd[name + ".2"], None, _new(*mid.shape, dt, dev), egate=mid, egate_act=RELU)
+            if name == "dconv_down1":
+                dw = torch.empty(shapes[0], **f32)
+                db = torch.empty(shapes[1], **f32)
+                K.conv3x3_c3_wgrad(xin, g_mid, dw, db, 1, code)
+                grads[(name, 0)] = (dw, db)
+                return g_mid
+            wgrad(name, 0, xin, g_mid)
+            if not need_dx:
+                return None
+            return K.conv3x3(g_mid, wd[name + ".0"], None, _new(*xin.shape, dt, dev))
+
+        # head: dx gated by ReLU'(u1b)
+        gout = gout.float().contiguous()
+        g_u1b = _new(n, 64, h, w, dt, dev)
+        dw_last = torch.empty((3, 64), **f32)
+        db_last = torch.empty((3,), **f32)
+        K.conv1x1_tanh_bwd(gout, out, u1b, w3c, g_u1b, dw_last, db_last, x_gate_act=RELU)
+
+        # decoder level 1
+        g_cat1 = block_bwd("dconv_up1", cat1, u1a, g_u1b)
+        g_u2b = _new(*u2b.shape, dt, dev)
+        dys1, dym1 = K.adain_upcat_bwd(g_cat1, u2b, st1, ys1, g_u2b, p_drop, seeds[2], mb1, x_gate_act=RELU)
+        # decoder level 2
+        g_cat2 = block_bwd("dconv_up2", cat2, u2a, g_u2b)
+        g_u3b = _new(*u3b.shape, dt, dev)
+        dys2, dym2 = K.adain_upcat_bwd(g_cat2, u3b, st2, ys2, g_u3b, p_drop, seeds[1], mb2, x_gate_act=RELU)
+        # decoder level 3
+        g_cat3 = block_bwd("dconv_up3", cat3, u3a, g_u3b)
+        g_b4 = _new(*b4.shape, dt, dev)
+        dys3, dym3 = K.adain_upcat_bwd(g_cat3, b4, st3, ys3, g_b4, p_drop, seeds[0], mb3, x_gate_act=RELU)
+        # bottleneck + encoder: max-pool backward fused with the skip-gradient sum and the ReLU gate
+        g_p3 = block_bwd("dconv_down4", p3, a4, g_b4)
+        conv3 = cat3[:, 512:]
+        g_conv3 = K.maxpool2_bwd(conv3, g_p3, _new(*conv3.shape, dt, dev), dskip=g_cat3[:, 512:], gate_act=RELU)
+        g_p2 = block_bwd("dconv_down3", p2, a3, g_conv3)
+        conv2 = cat2[:, 256:]
+        g_conv2 = K.maxpool2_bwd(conv2, g_p2, _new(*conv2.shape, dt, dev), dskip=g_cat2[:, 256:], gate_act=RELU)
+        g_p1 = block_bwd("dconv_down2", p1, a2, g_conv2)
+        conv1 = cat1[:, 128:]
+        g_conv1 = K.maxpool2_bwd(conv1, g_p1, _new(*conv1.shape, dt, dev), dskip=g_cat1[:, 128:], gate_act=RELU)
+        g_a1 = block_bwd("dconv_down1", x, a1, g_conv1)
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = torch.empty_like(x)
+            K.conv3x3_c3_dgrad(g_a1, w_first.contiguous(), dx, 1, code)
+
+        flat = []
+        for name in BLOCKS:
+            for j in (0, 2):
+                flat.extend(grads[(name, j)])
+        flat.append(dw_last.view(shapes[28]))
+        flat.append(db_last)
+        return (None, dx, dys3, dym3, dys2, dym2, dys1, dym1, *flat)
+
+
+def unet_forward(net, x, c):
+    """Run ``Conditional_UNet`` `net` through the fused graph (called by its forward)."""
+    code = precision_code(net.precision)
+    c = c.to(device=x.device, dtype=torch.float32)
+    styles = []
+    for adain in (net.adain3, net.adain2, net.adain1):
+        styles.extend(adain.style(c))
+    params, packed = [], []
+    for name in BLOCKS:
+        blk = getattr(net, name)
+        params.extend((blk[0].weight, blk[0].bias, blk[2].weight, blk[2].bias))
+        packed.extend((blk[0]._packed, blk[2]._packed))
+    params.extend((net.conv_last.weight, net.conv_last.bias))
+    p = net.dropout.p if net.training else 0.0
+    seeds = tuple(net._next_seed(k) for k in (3, 2, 1))
+    meta = (code, float(p), seeds, float(net.adain3.eps), packed)
+    return UNetFn.apply(meta, x, *styles, *params)
