@@ -217,41 +217,51 @@ __global__ __launch_bounds__(256) void adain_upcat_fwd_kernel(const T* __restric
     if (idx >= W2 * cpp) return;
     const int ow = idx / cpp, ch = idx - ow * cpp;
     const Lerp lx = src_index(ow, sx, W);
-    for (int row = blockIdx.y; row < N * H2; row += gridDim.y) {
-        const int n = row / H2, oh = row - n * H2;
-        const Lerp ly = src_index(oh, sy, H);
-        const T* b = x + (size_t)n * H * W * ldx + ch * E;
-        float v00[E], v01[E], v10[E], v11[E], o[E];
-        unpack16<T>(*(const uint4*)(b + (size_t)(ly.i0 * W + lx.i0) * ldx), v00);
-        unpack16<T>(*(const uint4*)(b + (size_t)(ly.i0 * W + lx.i1) * ldx), v01);
-        unpack16<T>(*(const uint4*)(b + (size_t)(ly.i1 * W + lx.i0) * ldx), v10);
-        unpack16<T>(*(const uint4*)(b + (size_t)(ly.i1 * W + lx.i1) * ldx), v11);
-        const size_t opix = (size_t)row * W2 + ow;
-        bool keep[E];
-        if (thr < 0x10000u) {
-            keep_bits<E>(seed, (uint64_t)opix * C + ch * E, thr, keep);
-            if (mbits) {            // one byte per 16-B chunk: backward reads the mask instead of re-hashing
-                uint32_t bits = 0;
-#pragma unroll
-                for (int e = 0; e < E; ++e) bits |= (keep[e] ? 1u : 0u) << e;
-                mbits[opix * cpp + ch] = (uint8_t)bits;
-            }
-        }
+    constexpr int RPT = 4;                           // consecutive output rows per thread (same image)
+    const int groups = (H2 + RPT - 1) / RPT;
+    for (int gy = blockIdx.y; gy < N * groups; gy += gridDim.y) {
+        const int n = gy / groups, oh_base = (gy - n * groups) * RPT;
         const int sc = n * C + ch * E;
-        float st[2 * E], ys[E], ym[E];
+        float st[2 * E], ys[E], ym[E], ka[E], kb[E];
         ldf<2 * E>(stats + 2 * sc, st);
         ldf<E>(y_std + sc, ys);
         ldf<E>(y_mean + sc, ym);
-        const float w00 = ly.l0 * lx.l0, w01 = ly.l0 * lx.l1, w10 = ly.l1 * lx.l0, w11 = ly.l1 * lx.l1;
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const float v = ly.l0 * (lx.l0 * v00[e] + lx.l1 * v01[e]) + ly.l1 * (lx.l0 * v10[e] + lx.l1 * v11[e]);
-            float r = (v - st[2 * e]) * (st[2 * e + 1] * ys[e]) + ym[e];     // utils.py:49-50
-            if (thr < 0x10000u) r = keep[e] ? r * keep_scale : 0.f;          // nn.Dropout(p) train mode
-            o[e] = r;
+        for (int e = 0; e < E; ++e) {                // out = v * ka + kb   (utils.py:49-50 folded)
+            ka[e] = st[2 * e + 1] * ys[e];
+            kb[e] = ym[e] - st[2 * e] * ka[e];
         }
-        (void)w00; (void)w01; (void)w10; (void)w11;
-        *(uint4*)(y + opix * ldy + ch * E) = pack16<T>(o);
+        const T* b = x + (size_t)n * H * W * ldx + ch * E;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int oh = oh_base + r;
+            if (oh >= H2) break;
+            const Lerp ly = src_index(oh, sy, H);
+            float v00[E], v01[E], v10[E], v11[E], o[E];
+            unpack16<T>(*(const uint4*)(b + (size_t)(ly.i0 * W + lx.i0) * ldx), v00);
+            unpack16<T>(*(const uint4*)(b + (size_t)(ly.i0 * W + lx.i1) * ldx), v01);
+            unpack16<T>(*(const uint4*)(b + (size_t)(ly.i1 * W + lx.i0) * ldx), v10);
+            unpack16<T>(*(const uint4*)(b + (size_t)(ly.i1 * W + lx.i1) * ldx), v11);
+            const size_t opix = ((size_t)n * H2 + oh) * W2 + ow;
+            bool keep[E];
+            if (thr < 0x10000u) {
+                keep_bits<E>(seed, (uint64_t)opix * C + ch * E, thr, keep);
+                if (mbits) {        // one byte per 16-B chunk: backward reads the mask instead of re-hashing
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) bits |= (keep[e] ? 1u : 0u) << e;
+                    mbits[opix * cpp + ch] = (uint8_t)bits;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float v = ly.l0 * (lx.l0 * v00[e] + lx.l1 * v01[e]) + ly.l1 * (lx.l0 * v10[e] + lx.l1 * v11[e]);
+                float rr = v * ka[e] + kb[e];
+                if (thr < 0x10000u) rr = keep[e] ? rr * keep_scale : 0.f;     // nn.Dropout(p) train mode
+                o[e] = rr;
+            }
+            *(uint4*)(y + opix * ldy + ch * E) = pack16<T>(o);
+        }
     }
 }
 
@@ -282,40 +292,46 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_gather_kernel(
         float g[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) g[e] = 0.f;
-        // separable weights of the (at most 6 x 6) output pixels that interpolate from (yy, xx)
-        const int j0 = 2 * xx - 2, i0 = 2 * yy - 2;
-        float wxs[6];
+        // The output pixels that interpolate from (yy, xx) are rows 2yy-1 .. 2yy+2 x cols 2xx-1 .. 2xx+2 (scale
+        // (H-1)/(2H-1) < 1/2): 16 UNCONDITIONAL loads (clamped coordinates, zero weight outside) so all of them
+        // are in flight together instead of one dependent load per taken branch.
+        float wys[4], wxs[4];
+        int iys[4], jxs[4];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int j = j0 + k;
-            float wv = 0.f;
-            if (j >= 0 && j < W2) {
-                const Lerp lx = src_index(j, sx, W);
-                wv = (lx.i0 == xx ? lx.l0 : 0.f) + (lx.i1 == xx ? lx.l1 : 0.f);
-            }
-            wxs[k] = wv;
+        for (int k = 0; k < 4; ++k) {
+            const int i = 2 * yy - 1 + k, j = 2 * xx - 1 + k;
+            const int ic = min(max(i, 0), H2 - 1), jc = min(max(j, 0), W2 - 1);
+            const Lerp ly = src_index(ic, sy, H), lx = src_index(jc, sx, W);
+            wys[k] = (i == ic) ? ((ly.i0 == yy ? ly.l0 : 0.f) + (ly.i1 == yy ? ly.l1 : 0.f)) : 0.f;
+            wxs[k] = (j == jc) ? ((lx.i0 == xx ? lx.l0 : 0.f) + (lx.i1 == xx ? lx.l1 : 0.f)) : 0.f;
+            iys[k] = ic;
+            jxs[k] = jc;
         }
+        uint4 dv[16];
+        uint32_t bv[16];
 #pragma unroll
-        for (int ki = 0; ki < 6; ++ki) {
-            const int i = i0 + ki;
-            if (i < 0 || i >= H2) continue;
-            const Lerp ly = src_index(i, sy, H);
-            const float wy = (ly.i0 == yy ? ly.l0 : 0.f) + (ly.i1 == yy ? ly.l1 : 0.f);
-            if (wy == 0.f) continue;
+        for (int ka = 0; ka < 4; ++ka)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                if (wxs[k] == 0.f) continue;
-                const size_t opix = (size_t)(n * H2 + i) * W2 + (j0 + k);
+            for (int kb = 0; kb < 4; ++kb) {
+                const size_t opix = (size_t)(n * H2 + iys[ka]) * W2 + jxs[kb];
+                dv[ka * 4 + kb] = *(const uint4*)(dy + opix * lddy + c0);
+                if (thr < 0x10000u && mbits) bv[ka * 4 + kb] = mbits[opix * cpp + chunk];
+            }
+#pragma unroll
+        for (int ka = 0; ka < 4; ++ka)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const float wgt = wys[ka] * wxs[kb];
                 float d[E];
-                unpack16<T>(*(const uint4*)(dy + opix * lddy + c0), d);
-                const float wgt = wy * wxs[k];
+                unpack16<T>(dv[ka * 4 + kb], d);
                 if (thr < 0x10000u) {
                     if (mbits) {
-                        const uint32_t bits = mbits[opix * cpp + chunk];
+                        const uint32_t bits = bv[ka * 4 + kb];
 #pragma unroll
                         for (int e = 0; e < E; ++e) g[e] += ((bits >> e) & 1u) ? wgt * d[e] : 0.f;
                     } else {
                         bool keep[E];
+                        const size_t opix = (size_t)(n * H2 + iys[ka]) * W2 + jxs[kb];
                         keep_bits<E>(seed, (uint64_t)opix * C + c0, thr, keep);
 #pragma unroll
                         for (int e = 0; e < E; ++e) g[e] += keep[e] ? wgt * d[e] : 0.f;
@@ -325,7 +341,6 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_gather_kernel(
                     for (int e = 0; e < E; ++e) g[e] += wgt * d[e];
                 }
             }
-        }
         if (thr < 0x10000u) {
 #pragma unroll
             for (int e = 0; e < E; ++e) g[e] *= keep_scale;
@@ -588,7 +603,7 @@ extern "C" int wu_adain_upcat_fwd(const void* x, int ldx, const float* stats, co
     WU_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "adain_upcat_fwd: p_drop");
     const float sy = (float)(H - 1) / (float)(2 * H - 1), sx = (float)(W - 1) / (float)(2 * W - 1);
     WU_REQUIRE(((uintptr_t)stats % 16) == 0 && ((uintptr_t)y_std % 16) == 0 && ((uintptr_t)y_mean % 16) == 0, "adain_upcat_fwd: stats alignment");
-    const int rows = N * 2 * H;
+    const int rows = N * cdiv(2 * H, 4);            // 4 output rows per thread
     const dim3 grid(cdiv(2 * W * (C / (16 / esz)), 256), rows < 32768 ? rows : 32768);
     DISPATCH_T(dtype, hipLaunchKernelGGL(adain_upcat_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
                                          (const T*)x, ldx, stats, y_std, y_mean, (T*)y, ldy, N, H, W, C, sy, sx,
