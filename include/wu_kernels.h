@@ -41,6 +41,12 @@ extern "C" {
 
 const char* wu_last_error(void);
 int wu_version(void);
+/* Kernel-variant switches for in-process A/B benchmarking (0: conv LDS-DMA path on/off, 1: persistent tile loop
+ * on/off, 2: LDS-DMA wgrad on/off).  Defaults = production choices; results are identical either way. */
+int wu_set_option(int key, int value);
+/* Diagnostic: device buffer of 256*8*8 uint64 receiving per-wave phase cycle sums of the persistent conv kernel
+ * (wait, compute, epilogue barrier/LDS write/barrier/stores, tiles, chunks); NULL (default) disables stamping. */
+int wu_set_debug_buffer(void* p);
 
 /* ---- weights -------------------------------------------------------------------------------
  * Repack one 3x3 conv weight (nets.py:20,22,28-31; OIHW fp32, the state-dict layout) into the two

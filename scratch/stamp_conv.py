@@ -1,0 +1,25 @@
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'weather-unet_amd'))
+import torch
+from wu import _lib, kernels as K
+from wu.layout import empty_nhwc
+dev = torch.device('cuda:0'); B = 32
+dbg = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
+for name, ci, co, s in [('d1.2', 64, 64, 256), ('d2.2', 128, 128, 128), ('d4.2', 512, 512, 32), ('u1.0', 192, 64, 256)]:
+    x = (torch.rand((B, s, s, ci), device=dev) * 2 - 1).to(torch.bfloat16).permute(0, 3, 1, 2)
+    w = ((torch.rand((co, ci, 3, 3), device=dev) * 2 - 1) * 0.05)
+    wf, wd = K.pack_conv3x3(w, 1); bias = torch.zeros(co, device=dev)
+    y = empty_nhwc(B, co, s, s, torch.bfloat16, dev)
+    for _ in range(3): K.conv3x3(x, wf, bias, y, 1, 1)
+    torch.cuda.synchronize()
+    _lib.call('wu_set_debug_buffer', dbg.data_ptr()); dbg.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); K.conv3x3(x, wf, bias, y, 1, 1); e1.record(); torch.cuda.synchronize()
+    _lib.call('wu_set_debug_buffer', None)
+    d = dbg.view(256, 8, 8).double().cpu()
+    tiles, chunks = d[0, 0, 6].item(), d[0, 0, 7].item()
+    ph = d[:, :, :6].mean(dim=(0, 1))
+    tot = ph.sum().item()
+    names = ['wait+barrier', 'compute', 'epi barrier1', 'epi LDS write', 'epi barrier2', 'epi stores']
+    print(f"{name}: kernel {e0.elapsed_time(e1)*1e3:.0f} us, tiles/WG {tiles:.0f}, chunks {chunks:.0f}; cycles per tile: " +
+          ", ".join(f"{n} {v/tiles:.0f}" for n, v in zip(names, ph.tolist())) + f"; total/tile {tot/tiles:.0f} cyc; compute/chunk {ph[1].item()/tiles/chunks:.0f}")

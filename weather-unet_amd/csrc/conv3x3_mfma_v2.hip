@@ -11,6 +11,8 @@
 //   * the DMA issue of the next chunk is spread over the nine taps of the current one (its address VALU work
 //     hides behind the MFMAs instead of sitting between the barrier and the first fragment read);
 //   * tile width fixed at 32: fragment addresses are lane_base[kw][ks] + immediate, no VALU in the tap loop.
+#include <type_traits>
+
 #include "wu_common.h"
 #include "conv_internal.h"
 
@@ -35,7 +37,8 @@ struct V2Args {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; const bf16_t* egate;
     int ldx, ldy, ldegate, egate_act;
     int N, H, W, Cin, Cout, act;
-    int tiles_x, tiles_y, cout_tiles;
+    int tiles_x, tiles_y, cout_tiles, ntiles;
+    unsigned long long* dbg;     // diagnostic: per-workgroup phase cycle sums (NULL in production)
 };
 
 // LDS-DMA issued from inline asm: hipcc cannot see it, so it neither drains it (vmcnt(0)) before the next
@@ -57,36 +60,52 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
 
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int ct = bid % a.cout_tiles; bid /= a.cout_tiles;
-    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y;
-    const int n = bid / a.tiles_y;
-    const int oh0 = ty * K::TH, ow0 = tx * K::TW, co0 = ct * 64;
+    // ---- persistent workgroup: a contiguous range of (n, ty, tx, cout-tile) items, cout-tile fastest ----
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int t_begin = (int)((long long)a.ntiles * wg / gridDim.x);
+    const int t_end = (int)((long long)a.ntiles * (wg + 1) / gridDim.x);
+    if (t_begin >= t_end) return;
 
-    // ---- per-lane DMA sources (fixed for the whole kernel; only the channel chunk offset moves) ----
-    // halo: LDS slot i = piece*64 + lane -> pixel p = i >> 2, LDS 16-B slot sl = i & 3 holds channel slot sl ^ swz(hx)
-    const bf16_t* xin = a.x + (size_t)n * a.H * a.W * a.ldx;
-    int hsrc[K::NH];                     // element offset inside image n, -1 = zero fill
+    // ---- tile-invariant parts of the DMA descriptors: LDS slot i = piece*64 + lane ----
+    // halo: pixel p = i >> 2, LDS 16-B slot sl = i & 3 holds channel slot sl ^ swz(hx); packed (hy << 8 | hx | s << 16), -1 = never valid
+    int hdesc[K::NH];
 #pragma unroll
     for (int j = 0; j < K::NH; ++j) {
         const int i = (K::NW * j + wave) * 64 + lane;
         const int p = i >> 2, sl = i & 3;
         const int hy = p / K::HALO_W, hx = p - hy * K::HALO_W;
-        const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
-        const int s = sl ^ ((hx >> 2) & 3);
-        hsrc[j] = (p < K::HALO_PIX && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) ? (ih * a.W + iw) * a.ldx + s * 8 : -1;
+        hdesc[j] = (p < K::HALO_PIX) ? ((hy << 8) | hx | ((sl ^ ((hx >> 2) & 3)) << 16)) : -1;
     }
-    // weights: LDS slot i -> row = i >> 2 = tap*64 + co, slot sl holds channel slot sl ^ swz(co)
-    int wsrc[K::NWT];
+    // weights: row = i >> 2 = tap*64 + co, slot sl holds channel slot sl ^ swz(co): element offset relative to cout tile 0
+    int wrel[K::NWT];
 #pragma unroll
     for (int j = 0; j < K::NWT; ++j) {
         const int i = (K::NW * j + wave) * 64 + lane;
         const int row = i >> 2, sl = i & 3;
         const int tap = row >> 6, co = row & 63;
-        const int s = sl ^ ((co >> 2) & 3);
-        wsrc[j] = (tap * a.Cout + co0 + co) * a.Cin + s * 8;     // < 9*512*768 elements: fits int32
+        wrel[j] = (tap * a.Cout + co) * a.Cin + (sl ^ ((co >> 2) & 3)) * 8;     // < 9*512*768 elements: fits int32
     }
+
+    // descriptors of the tile whose chunks are currently being FETCHED (one tile ahead at tile boundaries)
+    int hsrc[K::NH];
+    const bf16_t* xin_f = nullptr;
+    const bf16_t* w_f = nullptr;
+    auto set_fetch_tile = [&](int tile) __attribute__((always_inline)) {
+        int tt = tile;
+        const int ct = tt % a.cout_tiles; tt /= a.cout_tiles;
+        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
+        const int ty = tt % a.tiles_y;
+        const int n = tt / a.tiles_y;
+        const int oh0 = ty * K::TH, ow0 = tx * K::TW;
+        xin_f = a.x + (size_t)n * a.H * a.W * a.ldx;
+        w_f = a.w + (size_t)ct * 64 * a.Cin;
+#pragma unroll
+        for (int j = 0; j < K::NH; ++j) {
+            const int hy = (hdesc[j] >> 8) & 255, hx = hdesc[j] & 255, s_ = (hdesc[j] >> 16) & 3;
+            const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+            hsrc[j] = (hdesc[j] >= 0 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) ? (ih * a.W + iw) * a.ldx + s_ * 8 : -1;
+        }
+    };
 
     const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     auto issue_piece = [&](int j, int c0, int buf) __attribute__((always_inline)) {
@@ -94,13 +113,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a)
         // j in [0, NH): halo piece; j in [NH, NH + NWT): weight piece (wave-uniform guards)
         if (j < K::NH) {
             if (K::NW * j + wave < K::H_PIECES) {
-                const void* g = hsrc[j] >= 0 ? (const void*)(xin + hsrc[j] + c0) : (const void*)&g_zero16v2;
+                const void* g = hsrc[j] >= 0 ? (const void*)(xin_f + hsrc[j] + c0) : (const void*)&g_zero16v2;
                 dma16(g, __builtin_amdgcn_readfirstlane(lds + (K::NW * j + wave) * 1024));
             }
         } else {
             const int jj = j - K::NH;
             if (K::NW * jj + wave < K::W_PIECES)
-                dma16((const void*)(a.w + wsrc[jj] + c0), __builtin_amdgcn_readfirstlane(lds + K::H_BYTES + (K::NW * jj + wave) * 1024));
+                dma16((const void*)(w_f + wrel[jj] + c0), __builtin_amdgcn_readfirstlane(lds + K::H_BYTES + (K::NW * jj + wave) * 1024));
         }
     };
 
@@ -117,85 +136,145 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) b_lane[ks] = K::H_BYTES + l31 * 64 + (((2 * ks + lh) ^ ((l31 >> 2) & 3)) << 4);
 
-    f32x16_t acc[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
-
+    unsigned long long t_wait = 0, t_comp = 0, t_epi_b1 = 0, t_epi_w = 0, t_epi_b2 = 0, t_epi_s = 0, t_mark = 0;
+#define WU_STAMP(acc_var) do { if (a.dbg) { const unsigned long long t_ = __builtin_readcyclecounter(); acc_var += t_ - t_mark; t_mark = t_; } } while (0)
+    if (a.dbg) t_mark = __builtin_readcyclecounter();
     const int nchunks = a.Cin / 32;
+    int buf = 0;                                  // LDS buffer holding the chunk being computed
+    int stores_in_flight = 0;                     // 8 after an epilogue whose 8 store instructions all issued
+    set_fetch_tile(t_begin);
 #pragma unroll
     for (int j = 0; j < K::NH + K::NWT; ++j) issue_piece(j, 0, 0);
-    for (int c = 0; c < nchunks; ++c) {
-        const char* lds = smem + (c & 1) * K::BUF;
-        const int nxt = (c + 1) & 1;
-        const bool more = c + 1 < nchunks;
-        const int c1 = (c + 1) * 32;
-        dma_wait_all();      // this wave's pieces of chunk c have landed ...
-        __syncthreads();     // ... and so have everyone else's; everyone is also done with the other buffer
-        // 18 steps (tap, ks), software-pipelined by hand: the fragments of step s+1 are requested BEFORE the four
-        // MFMAs of step s are issued, so one LDS round trip is always covered by matrix work of this wave.
-        auto load_step = [&](int step, uint4 (&af)[2], uint4 (&bf)[2]) __attribute__((always_inline)) {
-            const int tap = step >> 1, ks = step & 1, kh = tap / 3, kw = tap % 3;
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        // accumulators are kept TRANSPOSED (rows = cout, cols = pixels: the weight fragment is the MFMA A operand):
+        // a lane then owns 4 consecutive channels of one pixel per register quad -> 8-byte epilogue writes
+        f32x16_t acc[2][2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                af[mi] = *(const uint4*)(lds + a_lane[kw][ks] + ((mi + kh) * K::HALO_W + kw) * 64);
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
-                bf[ni] = *(const uint4*)(lds + b_lane[ks] + (tap * 64 + 32 * ni) * 64);
-        };
-        uint4 af[2][2], bf[2][2];
-        load_step(0, af[0], bf[0]);
 #pragma unroll
-        for (int step = 0; step < 18; ++step) {
-            const int cur = step & 1;
-            if (step + 1 < 18) load_step(step + 1, af[cur ^ 1], bf[cur ^ 1]);
-            // spread the next chunk's DMA issue over the steps (10 pieces over 18 steps)
-            if (more && (step & 1) == 0) {
-                issue_piece(step >> 1, c1, nxt);
-                if (step == 16) issue_piece(9, c1, nxt);
-            }
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) mma(acc[mi][ni], af[cur][mi], bf[cur][ni]);
-        }
-    }
-    __syncthreads();
+                for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
-    // ---- epilogue: bias + activation in fp32, transpose through LDS, 16-B coalesced stores ----
-    constexpr int kRow = 64 * 2 + 16;
-    float bv[2] = {0.f, 0.f};
-    if (a.bias) {
-        bv[0] = a.bias[co0 + l31];
-        bv[1] = a.bias[co0 + 32 + l31];
-    }
+        // bias of this tile's 64 channels, in the transposed-accumulator layout (4 consecutive channels per register
+        // quad): requested HERE so the loads complete under the MFMAs instead of stalling the epilogue
+        float4 bvq[2][4];
+        {
+            const int ct_ = tile % a.cout_tiles;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = (2 * wave + mi) * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-                const float v = act_apply(acc[mi][ni][i] + bv[ni], a.act);
-                *((bf16_t*)(smem + row * kRow) + 32 * ni + l31) = f32_to_bf16(v);
-            }
-    __syncthreads();
-    bf16_t* yout = a.y + (size_t)n * a.H * a.W * a.ldy + co0;
-#pragma unroll
-    for (int k = 0; k < K::P * 8 / 512; ++k) {
-        const int q = tid + 512 * k;
-        const int r = q >> 3, s = q & 7;
-        const int oh = oh0 + (r >> 5), ow = ow0 + (r & 31);
-        if (oh < a.H && ow < a.W) {
-            uint4 v = *(const uint4*)(smem + r * kRow + s * 16);
-            if (a.egate)
-                v = gate16<bf16_t>(v, *(const uint4*)(a.egate + ((size_t)n * a.H * a.W + (size_t)(oh * a.W + ow)) * a.ldegate + co0 + s * 8), a.egate_act);
-            *(uint4*)(yout + (size_t)(oh * a.W + ow) * a.ldy + s * 8) = v;
+                for (int g = 0; g < 4; ++g)
+                    bvq[ni][g] = a.bias ? *(const float4*)(a.bias + ct_ * 64 + 32 * ni + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        for (int c = 0; c < nchunks; ++c) {
+            const char* lds = smem + buf * K::BUF;
+            const int nxt = buf ^ 1;
+            // what to fetch while computing this chunk: the next chunk of this tile, or chunk 0 of the next tile
+            const bool last = c + 1 == nchunks;
+            const bool more = !last || tile + 1 < t_end;
+            const int c1 = last ? 0 : (c + 1) * 32;
+            // this wave's pieces of the current chunk must have landed.  Right after an interior tile's epilogue the 8
+            // output stores are the YOUNGEST vector-memory ops and every DMA piece is older: vmcnt(8) retires the DMA
+            // without draining the stores to HBM (vmcnt counts loads, stores and LDS-DMA together, in issue order).
+            if (stores_in_flight == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else dma_wait_all();
+            stores_in_flight = 0;
+            __syncthreads();     // ... and so have everyone else's; everyone is also done with the other buffer
+            WU_STAMP(t_wait);
+            if (last && more) set_fetch_tile(tile + 1);
+            // 18 steps (tap, ks), software-pipelined by hand: the fragments of step s+1 are requested BEFORE the four
+            // MFMAs of step s are issued, so one LDS round trip is always covered by matrix work of this wave.
+            auto load_step = [&](int step, uint4 (&af)[2], uint4 (&bf)[2]) __attribute__((always_inline)) {
+                const int tap = step >> 1, ks = step & 1, kh = tap / 3, kw = tap % 3;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    af[mi] = *(const uint4*)(lds + a_lane[kw][ks] + ((mi + kh) * K::HALO_W + kw) * 64);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    bf[ni] = *(const uint4*)(lds + b_lane[ks] + (tap * 64 + 32 * ni) * 64);
+            };
+            uint4 af[2][2], bf[2][2];
+            load_step(0, af[0], bf[0]);
+#pragma unroll
+            for (int step = 0; step < 18; ++step) {
+                const int cur = step & 1;
+                if (step + 1 < 18) load_step(step + 1, af[cur ^ 1], bf[cur ^ 1]);
+                // issue the next chunk's 10 DMA pieces at the START of this chunk (2 per step, steps 0..4): their address
+                // VALU work hides behind MFMAs and they get ~3/4 of the chunk to land (LDS-DMA latency ~1.2 us)
+                if (more && step <= 4) {
+                    issue_piece(2 * step, c1, nxt);
+                    issue_piece(2 * step + 1, c1, nxt);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) mma(acc[mi][ni], bf[cur][ni], af[cur][mi]);   // D^T = W * X^T
+            }
+            buf = nxt;
+            WU_STAMP(t_comp);
+        }
+
+        // ---- epilogue of this tile (its last chunk sat in buffer buf^1, now free; buffer `buf` is receiving the next
+        //      tile's chunk 0): bias + activation in fp32, [pixel][cout] image through LDS, 16-B coalesced stores ----
+        int tt = tile;
+        const int ct = tt % a.cout_tiles; tt /= a.cout_tiles;
+        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
+        const int ty = tt % a.tiles_y;
+        const int n = tt / a.tiles_y;
+        const int oh0 = ty * K::TH, ow0 = tx * K::TW, co0 = ct * 64;
+        char* epi = smem + (buf ^ 1) * K::BUF;
+        constexpr int kRow = 64 * 2 + 16;
+        __syncthreads();         // every wave is done reading the last chunk
+        WU_STAMP(t_epi_b1);
+        // the activation is selected ONCE per tile (a per-element runtime switch costs a scalar branch per value)
+        auto epi_write = [&](auto act_tag) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    // registers 4g..4g+3 = channels 32*ni + 8g + 4*lh + (0..3) of pixel column l31
+                    const int cb = 32 * ni + 8 * g + 4 * lh;
+                    const float4 bv = bvq[ni][g];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        const int row = (2 * wave + mi) * 32 + l31;
+                        const uint32_t lo = pack_bf16x2(act_apply(acc[mi][ni][4 * g + 0] + bv.x, ACT), act_apply(acc[mi][ni][4 * g + 1] + bv.y, ACT));
+                        const uint32_t hi = pack_bf16x2(act_apply(acc[mi][ni][4 * g + 2] + bv.z, ACT), act_apply(acc[mi][ni][4 * g + 3] + bv.w, ACT));
+                        *(uint2*)(epi + row * kRow + cb * 2) = make_uint2(lo, hi);
+                    }
+                }
+        };
+        if (a.act == WU_ACT_RELU) epi_write(std::integral_constant<int, WU_ACT_RELU>{});
+        else if (a.act == WU_ACT_LEAKY) epi_write(std::integral_constant<int, WU_ACT_LEAKY>{});
+        else epi_write(std::integral_constant<int, WU_ACT_NONE>{});
+        WU_STAMP(t_epi_w);
+        __syncthreads();
+        WU_STAMP(t_epi_b2);
+        bf16_t* yout = a.y + (size_t)n * a.H * a.W * a.ldy + co0;
+#pragma unroll
+        for (int k = 0; k < K::P * 8 / 512; ++k) {
+            const int q = tid + 512 * k;
+            const int r = q >> 3, s = q & 7;
+            const int oh = oh0 + (r >> 5), ow = ow0 + (r & 31);
+            if (oh < a.H && ow < a.W) {
+                uint4 v = *(const uint4*)(epi + r * kRow + s * 16);
+                if (a.egate)
+                    v = gate16<bf16_t>(v, *(const uint4*)(a.egate + ((size_t)n * a.H * a.W + (size_t)(oh * a.W + ow)) * a.ldegate + co0 + s * 8), a.egate_act);
+                *(uint4*)(yout + (size_t)(oh * a.W + ow) * a.ldy + s * 8) = v;
+            }
+        }
+        // the next chunk's top barrier orders these LDS reads before that buffer is DMA'd into again
+        stores_in_flight = (oh0 + K::TH <= a.H && ow0 + K::TW <= a.W) ? K::P * 8 / 512 : -1;
+        WU_STAMP(t_epi_s);
     }
+    if (a.dbg && lane == 0) {
+        unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+        d[0] = t_wait; d[1] = t_comp; d[2] = t_epi_b1; d[3] = t_epi_w; d[4] = t_epi_b2; d[5] = t_epi_s; d[6] = (unsigned long long)(t_end - t_begin); d[7] = nchunks;
+    }
+#undef WU_STAMP
 }
 
 }  // namespace
@@ -211,8 +290,12 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.egate = (const bf16_t*)egate;
     a.ldx = ldx; a.ldy = ldy; a.ldegate = ldegate; a.egate_act = egate_act; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act;
     a.tiles_x = cdiv(W, K::TW); a.tiles_y = cdiv(H, K::TH); a.cout_tiles = Cout / 64;
-    const long long grid = (long long)N * a.tiles_x * a.tiles_y * a.cout_tiles;
-    if (grid >= (1ll << 31)) return -1;
+    a.dbg = (unsigned long long*)g_wu_dbg_ptr;
+    const long long ntiles = (long long)N * a.tiles_x * a.tiles_y * a.cout_tiles;
+    if (ntiles >= (1ll << 31)) return -1;
+    a.ntiles = (int)ntiles;
+    // persistent: one 8-wave workgroup per CU; each walks a contiguous tile range and prefetches across tiles
+    const long long grid = (ntiles < 256 || !g_wu_opt[WU_OPT_CONV_PERSISTENT]) ? ntiles : 256;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

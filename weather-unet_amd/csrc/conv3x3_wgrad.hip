@@ -275,7 +275,7 @@ extern "C" int wu_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy
     const int fam = stride == 2 ? WU_FAM_WGRAD_S2 : WU_FAM_WGRAD;
     const double flops = 2.0 * N * ((H - 1) / stride + 1) * ((W - 1) / stride + 1) * 9.0 * Cin * Cout;
     const double bytes = ((double)N * H * W * Cin + (double)N * ((H - 1) / stride + 1) * ((W - 1) / stride + 1) * Cout * (y ? 2 : 1)) * esz + 9.0 * Cin * Cout * 4;
-    if (wgrad_v2_eligible(H, W, Cin, Cout, stride, dtype, y != nullptr)) {
+    if (g_wu_opt[WU_OPT_WGRAD_V2] && wgrad_v2_eligible(H, W, Cin, Cout, stride, dtype, y != nullptr)) {
         const WgradV2Plan p2 = wgrad_v2_plan(N, H, W, Cin, Cout);
         WU_REQUIRE(workspace && workspace_bytes >= p2.ws && ((uintptr_t)workspace % 16) == 0, "conv3x3_wgrad: workspace too small (%zu < %zu)", workspace_bytes, p2.ws);
         WU_REQUIRE((size_t)H * W * (size_t)(ldx > lddy ? ldx : lddy) * 2 < (1ull << 31), "conv3x3_wgrad: image too large for 32-bit offsets");

@@ -30,6 +30,13 @@ extern thread_local char g_wu_err[256];
         if (e_ != hipSuccess) WU_FAIL((int)e_, "%s: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
+// ---- tuning switches (wu_prof.hip) ----
+extern int g_wu_opt[16];
+extern void* g_wu_dbg_ptr;
+#define WU_OPT_CONV_V2 0
+#define WU_OPT_CONV_PERSISTENT 1
+#define WU_OPT_WGRAD_V2 2
+
 // ---- profiling hooks (wu_prof.hip) --------------------------------------------------------------
 void wu_prof_pre(int family, hipStream_t s);
 void wu_prof_post(int family, hipStream_t s, double flops, double bytes);
@@ -88,12 +95,18 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v;
 }
 template <typename T> __device__ __forceinline__ uint4 gate16(const uint4& g, const uint4& y, int act) {
+    // the activation kind is tested once per 16-byte chunk, not per element (scalar branch per value otherwise)
     constexpr int n = ElemTraits<T>::kPer16B;
     float gf[n], yf[n];
     unpack16<T>(g, gf);
     unpack16<T>(y, yf);
+    if (act == WU_ACT_RELU) {
 #pragma unroll
-    for (int i = 0; i < n; ++i) gf[i] = act_gate(gf[i], yf[i], act);
+        for (int i = 0; i < n; ++i) gf[i] = yf[i] > 0.f ? gf[i] : 0.f;
+    } else if (act == WU_ACT_LEAKY) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) gf[i] = yf[i] > 0.f ? gf[i] : 0.2f * gf[i];
+    }
     return pack16<T>(gf);
 }
 

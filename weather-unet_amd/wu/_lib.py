@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libwu_kernels.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+OPT_CONV_V2, OPT_CONV_PERSISTENT, OPT_WGRAD_V2 = 0, 1, 2
 FAM_CONV_FWD, FAM_WGRAD, FAM_CONV_DGRAD, FAM_CONV_S2, FAM_WGRAD_S2 = 1, 2, 3, 4, 5
 FAMILY_KERNEL = {1: "conv3x3_mfma_kernel<T,1,false> (forward)", 2: "conv3x3_wgrad_kernel<T,1>",
                  3: "conv3x3_mfma_kernel<T,1,true> (dgrad)", 4: "conv3x3_mfma_kernel<T,2,false>", 5: "conv3x3_wgrad_kernel<T,2>"}
@@ -23,6 +24,8 @@ P, I, F, U64, SZ = c_void_p, c_int, c_float, c_uint64, c_size_t
 SIGNATURES = {
     "wu_last_error": (c_char_p, []),
     "wu_version": (I, []),
+    "wu_set_option": (I, [I, I]),
+    "wu_set_debug_buffer": (I, [P]),
     "wu_pack_conv3x3": (I, [P, P, P, I, I, P, I, P]),
     "wu_conv3x3_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P, I, I, P, I, I, I, P]),
     "wu_conv3x3_wgrad_workspace": (SZ, [I, I, I, I, I, I, I]),
