@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="inference forward (eval mode) instead of the training step")
+    ap.add_argument("--graph", action="store_true", help="with --fwd-only: replay a hipGraph-captured forward (configs[4])")
+    ap.add_argument("--workload", default="unet", choices=["unet", "gan-cls", "gan-est"],
+                    help="unet: cUNet fwd+bwd (the headline metric); gan-cls / gan-est: one full GAN iteration "
+                         "(D update + G update) of t_cls_train.py / t_est_train.py (configs[2] / configs[3])")
     return ap.parse_args()
 
 
@@ -90,9 +94,21 @@ def main():
     x = (torch.rand((a.batch, 3, a.size, a.size), generator=g) * 2 - 1).to(dev)
     c = torch.eye(5)[(torch.arange(a.batch) + rank * a.batch) % 5].to(dev)
 
-    if a.fwd_only:
+    graphed = None
+    gan = None
+    if a.workload != "unet":
+        from wu.train_step import WeatherTransferStep
+        gan = WeatherTransferStep(5, mode=a.workload[4:], precision=a.precision, device=dev, ddp=(world > 1), seed=0)
+        x_rand = (torch.rand((a.batch, 3, a.size, a.size), generator=g) * 2 - 1).to(dev)
+        reducer = opt = None
+    elif a.fwd_only:
         net.eval()
         reducer = opt = None
+        if a.graph:
+            from wu.graph_infer import GraphedUNet
+            graphed = GraphedUNet(net, a.batch, a.size)
+            graphed.x.copy_(x)
+            graphed.c.copy_(c)
     else:
         net.train()                            # Dropout(0.3) active, as in training (cunet.py:28)
         params = list(net.parameters())
@@ -100,7 +116,11 @@ def main():
         opt = torch.optim.Adam(params, lr=1e-4, betas=(0.0, 0.999), weight_decay=1e-4 / 20, fused=True)   # t_cls_train.py:184
 
     def step():
+        if gan is not None:
+            return gan.step(x, x_rand)
         if a.fwd_only:
+            if graphed is not None:
+                return graphed.replay()
             with torch.no_grad():
                 return net(x, c)
         if reducer is not None:
@@ -160,12 +180,16 @@ def main():
         imgs = a.batch * world * a.steps
         value = imgs / dt
         res = {
-            "metric": "images/sec 256x256 cUNet fwd+bwd" if not a.fwd_only else "images/sec cUNet forward (eval)",
+            "metric": ("images/sec GAN iteration (D update + G update)" if gan is not None else
+                       "images/sec 256x256 cUNet fwd+bwd" if not a.fwd_only else "images/sec cUNet forward (eval)"),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": (f"cUNet {a.size}x{a.size} {a.precision} B={a.batch}/GPU, "
-                                    + ("forward only (eval)" if a.fwd_only else
+            "config": {"workload": (f"{'t_' + a.workload[4:] + '_train GAN loop (cUNet + SNDisc + stand-in estimator)' if gan is not None else 'cUNet'} "
+                                    f"{a.size}x{a.size} {a.precision} B={a.batch}/GPU, "
+                                    + ("D update (2 D fwd+bwd, 1 G fwd) + G update (G fwd+bwd, D fwd + data-grad, estimator fwd+data-grad), 2x fused Adam"
+                                       if gan is not None else
+                                       ("forward only (eval)" + (", hipGraph replay" if a.graph else "")) if a.fwd_only else
                                        "training step: fwd + bwd (dgrad+wgrad) + grad all-reduce + fused Adam; dropout p=0.3 on; "
                                        "random-init weights, 5-class one-hot, loss mean|G(x,c)-x|")),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
@@ -174,7 +198,7 @@ def main():
         }
         if roof is not None:
             res["roofline"] = roof
-        if world == 1 and not a.no_cpu_baseline and not a.fwd_only:
+        if world == 1 and not a.no_cpu_baseline and not a.fwd_only and gan is None:
             res["cpu_baseline"] = cpu_baseline(a.size)
         print(json.dumps(res), flush=True)
     if world > 1:

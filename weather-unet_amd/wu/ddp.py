@@ -60,6 +60,7 @@ class GradBucketReducer:
         backend = dist.get_backend(group) if dist.is_initialized() else None
         self._avg_op = backend == "nccl"       # RCCL has a native AVG; gloo needs SUM + scale
         self.launch_log = []                   # bucket indices in launch order (tests / tracing)
+        self.enabled = True                    # False: gradients deposited by a backward are ignored (not reduced)
         if broadcast and self.world > 1:
             self.broadcast_parameters()
 
@@ -100,6 +101,8 @@ class GradBucketReducer:
             b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
 
     def _on_grad_ready(self, p):
+        if not self.enabled:
+            return
         bi = self._bucket_of[p]
         b = self.buckets[bi]
         if p.grad.data_ptr() < b["flat"].data_ptr() or p.grad.data_ptr() >= b["flat"].data_ptr() + b["flat"].numel() * 4:
