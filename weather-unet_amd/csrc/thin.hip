@@ -286,6 +286,128 @@ __global__ __launch_bounds__(256) void conv3x3_c3_dgrad_kernel(const void* __res
     }
 }
 
+// Data gradient wrt the image for NHWC dy with Cout % (elements per 16 B) == 0 (the 3->64 convs): LP lanes share
+// one INPUT pixel, each owning 16 B of dy channels; per contributing tap one coalesced 16-B load + 3 partial dot
+// products against the LDS-resident weights, finished with xor-shuffles.  Memory-bound (dy read ~once from L2).
+template <typename T, int STRIDE>
+__global__ __launch_bounds__(256) void conv3x3_c3_dgrad_nhwc_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
+                                                                    int act, const float* __restrict__ w, const float* __restrict__ inv_sigma,
+                                                                    float* __restrict__ dx, int N, int H, int W, int Cout, int accumulate) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [tap][ci][Cout]
+    const float sg = inv_sigma ? *inv_sigma : 1.f;
+    for (int i = threadIdx.x; i < 27 * Cout; i += 256) {
+        const int t = i / (3 * Cout), r = i - t * 3 * Cout, ci = r / Cout, co = r - ci * Cout;
+        wl[i] = w[co * 27 + ci * 9 + t] * sg;
+    }
+    __syncthreads();
+    const int LP = Cout / E;                     // lanes per pixel (8 for bf16 / 64 channels)
+    const int cl = threadIdx.x % LP;
+    const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
+    const long long total = (long long)N * H * W;
+    const int ppi = 256 / LP;
+    const long long iters = (total + ppi - 1) / ppi;
+    for (long long it = blockIdx.x; it < iters; it += gridDim.x) {
+        const long long pix = it * ppi + threadIdx.x / LP;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        int iw = 0, ih = 0, n = 0;
+        if (pix < total) {
+            iw = (int)(pix % W); ih = (int)((pix / W) % H); n = (int)(pix / ((long long)W * H));
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int th = ih + 1 - kh;
+                if (th < 0 || (th % STRIDE) || th / STRIDE >= Ho) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int tw = iw + 1 - kw;
+                    if (tw < 0 || (tw % STRIDE) || tw / STRIDE >= Wo) continue;
+                    const size_t op = ((size_t)n * Ho + th / STRIDE) * Wo + tw / STRIDE;
+                    uint4 gv = *(const uint4*)(dy + op * lddy + cl * E);
+                    if (y) gv = gate16<T>(gv, *(const uint4*)(y + op * ldy + cl * E), act);
+                    float g[E];
+                    unpack16<T>(gv, g);
+                    const float* wt = wl + (kh * 3 + kw) * 3 * Cout + cl * E;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        a0 += g[e] * wt[e];
+                        a1 += g[e] * wt[Cout + e];
+                        a2 += g[e] * wt[2 * Cout + e];
+                    }
+                }
+            }
+        }
+        for (int m = LP >> 1; m > 0; m >>= 1) {
+            a0 += __shfl_xor(a0, m); a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m);
+        }
+        if (cl == 0 && pix < total) {
+            const size_t hw = (size_t)H * W, o = (size_t)n * 3 * hw + (size_t)ih * W + iw;
+            if (accumulate) { dx[o] += a0; dx[o + hw] += a1; dx[o + 2 * hw] += a2; }
+            else { dx[o] = a0; dx[o + hw] = a1; dx[o + 2 * hw] = a2; }
+        }
+    }
+}
+
+// Weight gradient of the 3->3 image-layout conv (disc.conv1[0]: NCHW fp32 dy, Cout <= 4): one thread per output
+// pixel accumulates all Cout*27 products in registers over a grid-stride loop; wave shuffle + LDS reduce; atomics.
+template <int STRIDE>
+__global__ __launch_bounds__(256) void conv3x3_c3_wgrad_small_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                     const float* __restrict__ y, int act, float* __restrict__ dw,
+                                                                     float* __restrict__ dbias, int N, int H, int W, int Cout) {
+    __shared__ float red[4][84];
+    const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
+    const long long total = (long long)N * Ho * Wo;
+    float acc[3][27], bs[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        bs[c] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[c][k] = 0.f;
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ow = (int)(i % Wo), oh = (int)((i / Wo) % Ho), n = (int)(i / ((long long)Wo * Ho));
+        float g[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            g[c] = 0.f;
+            if (c < Cout) {
+                const size_t o = (((size_t)n * Cout + c) * Ho + oh) * Wo + ow;
+                g[c] = dy[o];
+                if (y) g[c] = act_gate(g[c], y[o], act);
+            }
+            bs[c] += g[c];
+        }
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            const int ci = k / 9, t = k % 9, ih = oh * STRIDE + t / 3 - 1, iw = ow * STRIDE + t % 3 - 1;
+            const float v = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? x[(((size_t)n * 3 + ci) * H + ih) * W + iw] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c][k] += g[c] * v;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            float v = acc[c][k];
+            for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+            if (lane == 0) red[wave][c * 27 + k] = v;
+        }
+        float b = bs[c];
+        for (int m = 32; m > 0; m >>= 1) b += __shfl_xor(b, m);
+        if (lane == 0) red[wave][81 + c] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 84) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x < 81) {
+            if (threadIdx.x / 27 < Cout) atomicAdd(&dw[threadIdx.x], v);
+        } else if (dbias && threadIdx.x - 81 < Cout) {
+            atomicAdd(&dbias[threadIdx.x - 81], v);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // conv_last (1x1, Cin -> 3) + tanh.  LP lanes share one pixel (16 B of channels each): a wave load is
 // 64/LP full pixel rows; the three dot products are finished with xor-shuffles.
@@ -425,6 +547,13 @@ extern "C" int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy
         WU_LAUNCH_CHECK("conv3x3_c3_wgrad_mfma");
         return 0;
     }
+    if (dy_nchw && Cout <= 3) {
+        const int g = grid_cap((long long)N * Ho * Wo, 256, 1024);
+        if (stride == 1) hipLaunchKernelGGL(conv3x3_c3_wgrad_small_kernel<1>, dim3(g), dim3(256), 0, s, x_nchw, (const float*)dy, (const float*)y, act, dw_oihw, dbias, N, H, W, Cout);
+        else hipLaunchKernelGGL(conv3x3_c3_wgrad_small_kernel<2>, dim3(g), dim3(256), 0, s, x_nchw, (const float*)dy, (const float*)y, act, dw_oihw, dbias, N, H, W, Cout);
+        WU_LAUNCH_CHECK("conv3x3_c3_wgrad_small");
+        return 0;
+    }
     if (dy_nchw) { if (stride == 1) C3W(float, 1, true); else C3W(float, 2, true); }
     else if (dtype == WU_BF16) { if (stride == 1) C3W(bf16_t, 1, false); else C3W(bf16_t, 2, false); }
     else { if (stride == 1) C3W(float, 1, false); else C3W(float, 2, false); }
@@ -441,6 +570,18 @@ extern "C" int wu_conv3x3_c3_dgrad(const void* dy, int lddy, int dy_nchw, const 
     hipStream_t s = (hipStream_t)stream;
     const int grid = grid_cap((long long)N * H * W, 256, 256 * 32);
     const size_t lds = (size_t)27 * Cout * sizeof(float);
+    const int esz_ = dtype == WU_BF16 ? 2 : 4;
+    const int lp_ = dy_nchw ? 0 : Cout / (16 / esz_);
+    if (!dy_nchw && Cout % (16 / esz_) == 0 && lp_ >= 1 && lp_ <= 64 && (lp_ & (lp_ - 1)) == 0 && ((uintptr_t)dy % 16) == 0 && (lddy * esz_) % 16 == 0 &&
+        (!y || (((uintptr_t)y % 16) == 0 && (ldy_ * esz_) % 16 == 0))) {
+        const int g = grid_cap((long long)N * H * W, 256 / lp_, 256 * 16);
+#define C3DN(T, ST) hipLaunchKernelGGL((conv3x3_c3_dgrad_nhwc_kernel<T, ST>), dim3(g), dim3(256), lds, s, (const T*)dy, lddy, (const T*)y, ldy_, act, w_oihw, inv_sigma, dx_nchw, N, H, W, Cout, accumulate)
+        if (dtype == WU_BF16) { if (stride == 1) C3DN(bf16_t, 1); else C3DN(bf16_t, 2); }
+        else { if (stride == 1) C3DN(float, 1); else C3DN(float, 2); }
+#undef C3DN
+        WU_LAUNCH_CHECK("conv3x3_c3_dgrad_nhwc");
+        return 0;
+    }
 #define C3D(T, ST, NCHW) hipLaunchKernelGGL((conv3x3_c3_dgrad_kernel<T, ST, NCHW>), dim3(grid), dim3(256), lds, s, dy, lddy, y, ldy_, act, w_oihw, inv_sigma, dx_nchw, N, H, W, Cout, accumulate)
     if (dy_nchw) { if (stride == 1) C3D(float, 1, true); else C3D(float, 2, true); }
     else if (dtype == WU_BF16) { if (stride == 1) C3D(bf16_t, 1, false); else C3D(bf16_t, 2, false); }
