@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="inference forward (eval mode) instead of the training step")
     ap.add_argument("--graph", action="store_true", help="with --fwd-only: replay a hipGraph-captured forward (configs[4])")
+    ap.add_argument("--force-ddp", action="store_true", help="initialise RCCL and use the bucketed reducer even with one rank (test hook)")
     ap.add_argument("--workload", default="unet", choices=["unet", "gan-cls", "gan-est"],
                     help="unet: cUNet fwd+bwd (the headline metric); gan-cls / gan-est: one full GAN iteration "
                          "(D update + G update) of t_cls_train.py / t_est_train.py (configs[2] / configs[3])")
@@ -81,7 +82,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_ddp = world > 1 or a.force_ddp
+    if use_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import cunet
@@ -98,7 +102,7 @@ def main():
     gan = None
     if a.workload != "unet":
         from wu.train_step import WeatherTransferStep
-        gan = WeatherTransferStep(5, mode=a.workload[4:], precision=a.precision, device=dev, ddp=(world > 1), seed=0)
+        gan = WeatherTransferStep(5, mode=a.workload[4:], precision=a.precision, device=dev, ddp=use_ddp, seed=0)
         x_rand = (torch.rand((a.batch, 3, a.size, a.size), generator=g) * 2 - 1).to(dev)
         reducer = opt = None
     elif a.fwd_only:
@@ -112,7 +116,7 @@ def main():
     else:
         net.train()                            # Dropout(0.3) active, as in training (cunet.py:28)
         params = list(net.parameters())
-        reducer = GradBucketReducer(params, bucket_mb=12.0) if world > 1 else None
+        reducer = GradBucketReducer(params, bucket_mb=12.0) if use_ddp else None
         opt = torch.optim.Adam(params, lr=1e-4, betas=(0.0, 0.999), weight_decay=1e-4 / 20, fused=True)   # t_cls_train.py:184
 
     def step():
@@ -137,7 +141,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -153,7 +157,7 @@ def main():
         last = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_ddp:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -165,10 +169,22 @@ def main():
         dom = max(stats, key=lambda f: stats[f]["ms"])
         s = stats[dom]
         peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+        # HBM bytes per launch from the PMC counters: collected offline with rocprofv3 (separate --pmc passes, gfx950
+        # correction) and committed under profiles/ -- bench.py cannot run the profiler on itself
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            key = {_lib.FAM_CONV_FWD: "conv3x3_mfma_v2", _lib.FAM_WGRAD: "conv3x3_wgrad_v2"}.get(dom)
+            if key in pmc and a.precision == "bf16" and a.batch == 32 and a.size == 256 and a.workload == "unet" and not a.fwd_only:
+                traffic = pmc[key]["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         if s["launches"]:
             ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "kernel": _lib.FAMILY_KERNEL[dom], "launches": s["launches"],
+                    "traffic": traffic, "kernel": _lib.FAMILY_KERNEL[dom], "launches": s["launches"],
+                    "algorithmic_bytes_per_launch": round(s["bytes"] / s["launches"]),
                     "avg_launch_ms": round(s["ms"] / s["launches"], 4),
                     "algorithmic_gflop_per_launch": round(s["flops"] / s["launches"] / 1e9, 3),
                     "share_of_step": round(s["ms"] / (dt * 1e3), 3),
@@ -201,7 +217,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline and not a.fwd_only and gan is None:
             res["cpu_baseline"] = cpu_baseline(a.size)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_ddp:
         dist.destroy_process_group()
 
 

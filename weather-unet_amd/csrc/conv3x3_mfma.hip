@@ -16,6 +16,8 @@
 // LDS images: pixel-major, 64 B per pixel (one chunk), the four 16-B slots of a pixel XOR-swizzled
 // with (pixel >> 2) & 3 so a ds_read_b128 lane group touches 16 distinct slots (conflict-free for
 // TW = 32).  Same for the weight rows ([tap][cout] rows of 64 B).
+#include <type_traits>
+
 #include "wu_common.h"
 #include "conv_internal.h"
 
@@ -234,16 +236,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
         bv[0] = a.bias[co0 + l31];
         bv[1] = a.bias[co0 + 32 + l31];
     }
+    // the activation is selected once (a per-element runtime switch costs a scalar branch per value)
+    auto epi_write = [&](auto act_tag) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = 64 * wave + 32 * mi + (i & 3) + 8 * (i >> 2) + 4 * lh;
-                const float v = act_apply(acc[mi][ni][i] + bv[ni], a.act);
-                ElemTraits<T>::store((T*)(smem + row * kRow) + 32 * ni + l31, v);
-            }
+                for (int i = 0; i < 16; ++i) {
+                    const int row = 64 * wave + 32 * mi + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                    const float v = act_apply(acc[mi][ni][i] + bv[ni], ACT);
+                    ElemTraits<T>::store((T*)(smem + row * kRow) + 32 * ni + l31, v);
+                }
+    };
+    if (a.act == WU_ACT_RELU) epi_write(std::integral_constant<int, WU_ACT_RELU>{});
+    else if (a.act == WU_ACT_LEAKY) epi_write(std::integral_constant<int, WU_ACT_LEAKY>{});
+    else epi_write(std::integral_constant<int, WU_ACT_NONE>{});
     __syncthreads();
     constexpr int kSlotsPerRow = kBN * (int)sizeof(T) / 16;  // 8 (bf16) / 16 (fp32)
     T* yout = (T*)a.y + (size_t)n * a.Ho * a.Wo * a.ldy + co0;

@@ -37,7 +37,7 @@ struct V2Args {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; const bf16_t* egate;
     int ldx, ldy, ldegate, egate_act;
     int N, H, W, Cin, Cout, act;
-    int tiles_x, tiles_y, cout_tiles, ntiles;
+    int tiles_x, tiles_y, cout_tiles, ntiles, ct_slowest;
     unsigned long long* dbg;     // diagnostic: per-workgroup phase cycle sums (NULL in production)
 };
 
@@ -91,8 +91,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a)
     const bf16_t* xin_f = nullptr;
     const bf16_t* w_f = nullptr;
     auto set_fetch_tile = [&](int tile) __attribute__((always_inline)) {
-        int tt = tile;
-        const int ct = tt % a.cout_tiles; tt /= a.cout_tiles;
+        int tt = tile, ct;
+        if (a.ct_slowest) { const int per = a.ntiles / a.cout_tiles; ct = tt / per; tt -= ct * per; }
+        else { ct = tt % a.cout_tiles; tt /= a.cout_tiles; }
         const int tx = tt % a.tiles_x; tt /= a.tiles_x;
         const int ty = tt % a.tiles_y;
         const int n = tt / a.tiles_y;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a)
         // quad): requested HERE so the loads complete under the MFMAs instead of stalling the epilogue
         float4 bvq[2][4];
         {
-            const int ct_ = tile % a.cout_tiles;
+            const int ct_ = a.ct_slowest ? tile / (a.ntiles / a.cout_tiles) : tile % a.cout_tiles;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -181,11 +182,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a)
             if (stores_in_flight == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else dma_wait_all();
             stores_in_flight = 0;
-            __syncthreads();     // ... and so have everyone else's; everyone is also done with the other buffer
             WU_STAMP(t_wait);
+            __syncthreads();     // ... and so have everyone else's; everyone is also done with the other buffer
+            WU_STAMP(t_epi_b2);  // (diagnostic) chunk-top barrier time is folded into the 'barrier2' slot
             if (last && more) set_fetch_tile(tile + 1);
             // 18 steps (tap, ks), software-pipelined by hand: the fragments of step s+1 are requested BEFORE the four
-            // MFMAs of step s are issued, so one LDS round trip is always covered by matrix work of this wave.
+            // MFMAs of step s are issued, so one LDS round trip is always covered by matrix work of this wave
+            // (a 2-step look-ahead measured 2-3 % slower).
             auto load_step = [&](int step, uint4 (&af)[2], uint4 (&bf)[2]) __attribute__((always_inline)) {
                 const int tap = step >> 1, ks = step & 1, kh = tap / 3, kw = tap % 3;
 #pragma unroll
@@ -218,8 +221,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a)
 
         // ---- epilogue of this tile (its last chunk sat in buffer buf^1, now free; buffer `buf` is receiving the next
         //      tile's chunk 0): bias + activation in fp32, [pixel][cout] image through LDS, 16-B coalesced stores ----
-        int tt = tile;
-        const int ct = tt % a.cout_tiles; tt /= a.cout_tiles;
+        int tt = tile, ct;
+        if (a.ct_slowest) { const int per = a.ntiles / a.cout_tiles; ct = tt / per; tt -= ct * per; }
+        else { ct = tt % a.cout_tiles; tt /= a.cout_tiles; }
         const int tx = tt % a.tiles_x; tt /= a.tiles_x;
         const int ty = tt % a.tiles_y;
         const int n = tt / a.tiles_y;
@@ -291,6 +295,7 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     a.ldx = ldx; a.ldy = ldy; a.ldegate = ldegate; a.egate_act = egate_act; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act;
     a.tiles_x = cdiv(W, K::TW); a.tiles_y = cdiv(H, K::TH); a.cout_tiles = Cout / 64;
     a.dbg = (unsigned long long*)g_wu_dbg_ptr;
+    a.ct_slowest = g_wu_opt[WU_OPT_CONV_CT_SLOWEST];
     const long long ntiles = (long long)N * a.tiles_x * a.tiles_y * a.cout_tiles;
     if (ntiles >= (1ll << 31)) return -1;
     a.ntiles = (int)ntiles;

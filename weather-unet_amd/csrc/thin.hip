@@ -10,10 +10,10 @@ namespace {
 // conv3x3, Cin = 3, NCHW fp32 input.  One thread = one output pixel x all COUT channels; the 27 x COUT
 // weights sit in LDS and are read as wave-uniform (broadcast) float4s.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int COUT, int STRIDE, bool OUT_NCHW>
+template <typename T, int COUT, int STRIDE, bool OUT_NCHW, int ACT>
 __global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, const float* __restrict__ inv_sigma,
-                                                             void* __restrict__ yv, int ldy, int N, int H, int W, int act) {
+                                                             void* __restrict__ yv, int ldy, int N, int H, int W) {
     constexpr int CP = (COUT + 3) & ~3;
     __shared__ __attribute__((aligned(16))) float wl[27][CP];
     __shared__ float bl[CP];
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(const float* __rest
             }
         }
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[c] = act_apply(acc[c], act);
+        for (int c = 0; c < COUT; ++c) acc[c] = act_apply(acc[c], ACT);   // ACT is a compile-time constant here
         if (OUT_NCHW) {
             float* y = (float*)yv;
 #pragma unroll
@@ -517,10 +517,12 @@ extern "C" int wu_conv3x3_c3_fwd(const float* x_nchw, const float* w_oihw, const
     hipStream_t s = (hipStream_t)stream;
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const int grid = grid_cap((long long)N * Ho * Wo, 256, 256 * 32);
-#define C3_LAUNCH(T, CO, ST, NCHW) hipLaunchKernelGGL((conv3x3_c3_fwd_kernel<T, CO, ST, NCHW>), dim3(grid), dim3(256), 0, s, x_nchw, w_oihw, bias, inv_sigma, y, ldy, N, H, W, act)
+#define C3_LAUNCH_A(T, CO, ST, NCHW, A) hipLaunchKernelGGL((conv3x3_c3_fwd_kernel<T, CO, ST, NCHW, A>), dim3(grid), dim3(256), 0, s, x_nchw, w_oihw, bias, inv_sigma, y, ldy, N, H, W)
+#define C3_LAUNCH(T, CO, ST, NCHW) do { if (act == WU_ACT_RELU) C3_LAUNCH_A(T, CO, ST, NCHW, WU_ACT_RELU); else if (act == WU_ACT_LEAKY) C3_LAUNCH_A(T, CO, ST, NCHW, WU_ACT_LEAKY); else C3_LAUNCH_A(T, CO, ST, NCHW, WU_ACT_NONE); } while (0)
     if (out_nchw) C3_LAUNCH(float, 3, 1, true);
     else if (dtype == WU_BF16) { if (stride == 1) C3_LAUNCH(bf16_t, 64, 1, false); else C3_LAUNCH(bf16_t, 64, 2, false); }
     else { if (stride == 1) C3_LAUNCH(float, 64, 1, false); else C3_LAUNCH(float, 64, 2, false); }
+#undef C3_LAUNCH_A
 #undef C3_LAUNCH
     WU_LAUNCH_CHECK("conv3x3_c3_fwd");
     return 0;

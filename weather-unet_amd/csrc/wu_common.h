@@ -36,6 +36,7 @@ extern void* g_wu_dbg_ptr;
 #define WU_OPT_CONV_V2 0
 #define WU_OPT_CONV_PERSISTENT 1
 #define WU_OPT_WGRAD_V2 2
+#define WU_OPT_CONV_CT_SLOWEST 3
 
 // ---- profiling hooks (wu_prof.hip) --------------------------------------------------------------
 void wu_prof_pre(int family, hipStream_t s);

@@ -15,8 +15,10 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 OPT_CONV_V2, OPT_CONV_PERSISTENT, OPT_WGRAD_V2 = 0, 1, 2
 FAM_CONV_FWD, FAM_WGRAD, FAM_CONV_DGRAD, FAM_CONV_S2, FAM_WGRAD_S2 = 1, 2, 3, 4, 5
-FAMILY_KERNEL = {1: "conv3x3_mfma_kernel<T,1,false> (forward)", 2: "conv3x3_wgrad_kernel<T,1>",
-                 3: "conv3x3_mfma_kernel<T,1,true> (dgrad)", 4: "conv3x3_mfma_kernel<T,2,false>", 5: "conv3x3_wgrad_kernel<T,2>"}
+FAMILY_KERNEL = {1: "conv3x3_mfma_v2_kernel (forward + data-gradient convs; generic conv3x3_mfma_kernel for fp32 / narrow images)",
+                 2: "conv3x3_wgrad_v2_kernel (generic conv3x3_wgrad_kernel for fp32 / narrow images)",
+                 3: "conv3x3_mfma_kernel<T,1,true> (in-kernel gated dgrad; unused by the fused graph)",
+                 4: "conv3x3_mfma_kernel<T,2,false>", 5: "conv3x3_wgrad_kernel<T,2>"}
 
 P, I, F, U64, SZ = c_void_p, c_int, c_float, c_uint64, c_size_t
 
