@@ -351,3 +351,35 @@ def test_gan_step_matches_oracle():
         assert cos >= 0.995, f"G grad {k}: cos {cos}"
     assert all(p.grad is None or True for p in st.discriminator.parameters())
     print("GAN step: worst G-gradient cosine", worst)
+
+
+def test_checkpoint_interchange_and_class_sweep(tmp_path):
+    """reference-format checkpoints ({'inference','discriminator','epoch','global_step'}) round-trip
+    through save/load/resume, and the inf_transfer_c-style one-hot sweep equals per-class forwards."""
+    import cunet
+    import disc
+    from wu.graph_infer import GraphedUNet
+    from wu.infer_driver import class_sweep, latest_checkpoint, load_checkpoint, normalize_minmax, save_checkpoint
+    nc = 5
+    g, d = _make_g(nc, 11, "bf16").eval(), _make_d(nc, 11, "bf16")
+    save_checkpoint(str(tmp_path), "run", g, d, 3, 2000)
+    save_checkpoint(str(tmp_path), "run", g, d, 3, 3000)
+    last = latest_checkpoint(str(tmp_path), "run")
+    assert last.endswith("run_e0003_s3000.pt")
+    raw = torch.load(last, weights_only=True)
+    assert set(raw) == {"inference", "discriminator", "epoch", "global_step"}
+    assert set(raw["inference"]) == set(O.cunet_param_shapes(nc)) and set(raw["discriminator"]) == set(O.sndisc_param_shapes(nc))
+    g2, d2 = cunet.Conditional_UNet(nc).to(DEV).eval(), disc.SNDisc(nc).to(DEV)
+    assert load_checkpoint(last, g2, d2) == (3, 3000)
+    x, _ = O.make_inputs(2, 64, nc, 11, False)
+    xd = x.to(DEV)
+    sweep = class_sweep(g2, xd)
+    assert tuple(sweep.shape) == (nc, 2, 3, 64, 64)
+    eye = torch.eye(nc, device=DEV)
+    for i in range(nc):
+        with torch.no_grad():
+            ref = g(xd, eye[i].repeat(2, 1))
+        assert torch.equal(sweep[i], ref)
+    assert torch.equal(class_sweep(g2, xd, graphed=GraphedUNet(g2, 2, 64)), sweep)
+    nm = normalize_minmax(sweep[0])
+    assert nm.min().item() >= 0 and abs(nm.reshape(2, -1).max(dim=1).values - 1).max().item() < 1e-3

@@ -44,12 +44,18 @@ struct W2Args {
     int ldx, lddy;
     int N, H, W, Cin, Cout;
     int tiles_x, tiles_y, ntiles, tiles_per_split, splits, co_blocks, ci_blocks;
+    int dma_interleave;     // 1: spread the next tile's DMA issue over the first K-steps; 0: burst right after the barrier
 };
 
-__device__ __forceinline__ void dma16(const void* g, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// LDS-DMA from inline asm (see conv3x3_mfma_v2.hip): invisible to hipcc's waitcnt bookkeeping, so issuing it in the
+// middle of the MFMA loop does not make the compiler drain it before the next fragment read; the kernel waits for
+// it itself (dma_wait_all) ahead of the barrier that publishes the buffer.
+__device__ __forceinline__ void dma16(const void* g, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
 }
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint4 tr_frag(const char* p0) {
     const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)p0);
     const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p0 + 4 * 128));
@@ -62,10 +68,12 @@ __device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& 
 // tap owned by accumulator slot i (0..3) of tap-half HF; slot 4 is the centre tap (4)
 template <int HF> __device__ __forceinline__ constexpr int tap_of(int i) { return i == 4 ? 4 : (HF ? 5 + i : i); }
 
-template <int HF>
-__device__ __forceinline__ void compute_tile(const char* lds, const int (&a_lane)[2], const int (&b_lane)[3], f32x16_t (&acc)[9]) {
+template <int HF, typename Issue>
+__device__ __forceinline__ void compute_tile(const char* lds, const int (&a_lane)[2], const int (&b_lane)[3], f32x16_t (&acc)[9], Issue&& issue) {
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
+        // the next tile's DMA pieces are issued inside the first K-steps: their address arithmetic overlaps MFMAs
+        issue(kk);
         // K-step ks = 2*kk + parity covers tile pixels 32*kk + 16*parity + [0,16): tile row kk (parity is in the lane base)
         const int a_off = 32 * kk * C::DY_ROW;
         const int b_off = kk * C::HALO_W * 128;
@@ -119,34 +127,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
         x_d[j] = (p < C::HALO_PIX && C::NW * j + wave < C::X_PIECES) ? ((hy << 8) | hx | (s << 16)) : -1;
     }
 
-    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+    // DMA of one tile = NDY + NX pieces per wave; `set_fetch_tile` decodes the tile once, `issue_piece(j)` issues piece j
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const char* dyb_f = nullptr;
+    const char* xb_f = nullptr;
+    int oh0_f = 0, ow0_f = 0;
+    auto set_fetch_tile = [&](int tile) __attribute__((always_inline)) {
         int tt = tile;
         const int tx = tt % a.tiles_x; tt /= a.tiles_x;
         const int ty = tt % a.tiles_y;
         const int n = tt / a.tiles_y;
-        const int oh0 = ty * C::TH, ow0 = tx * 32;
-        char* lds = smem + buf * C::BUF;
-        const char* dyb = (const char*)(a.dy + ((size_t)n * a.H * a.W + (size_t)oh0 * a.W + ow0) * a.lddy + cob * 64);
+        oh0_f = ty * C::TH; ow0_f = tx * 32;
+        dyb_f = (const char*)(a.dy + ((size_t)n * a.H * a.W + (size_t)oh0_f * a.W + ow0_f) * a.lddy + cob * 64);
         // x halo origin (oh0-1, ow0-1) may lie outside the image: keep it as a signed element offset
-        const long long xo = ((long long)n * a.H * a.W + (long long)(oh0 - 1) * a.W + (ow0 - 1)) * a.ldx + cib * 64;
-        const char* xb = (const char*)a.x + xo * 2;
-        const int hrem = a.H - oh0, wrem = a.W - ow0;        // valid rows / cols left in this tile
-#pragma unroll
-        for (int j = 0; j < C::NDY; ++j) {
+        const long long xo = ((long long)n * a.H * a.W + (long long)(oh0_f - 1) * a.W + (ow0_f - 1)) * a.ldx + cib * 64;
+        xb_f = (const char*)a.x + xo * 2;
+    };
+    auto issue_piece = [&](int j, int buf) __attribute__((always_inline)) {
+        const unsigned lds = smem_base + buf * C::BUF;
+        if (j < C::NDY) {
             const int ty_ = (dy_d[j] >> 8) & 255, tx_ = dy_d[j] & 255, s_ = dy_d[j] >> 16;
             const int rel = ((ty_ * a.W + tx_) * a.lddy + s_ * 8) * 2;
-            const void* g = (ty_ < hrem && tx_ < wrem) ? (const void*)(dyb + rel) : (const void*)&g_zero16;
-            dma16(g, lds + (C::NW * j + wave) * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < C::NX; ++j) {
-            if (C::NW * j + wave < C::X_PIECES) {             // wave-uniform
-                const int hy = (x_d[j] >> 8) & 255, hx = x_d[j] & 255, s_ = (x_d[j] >> 16) & 15;
-                const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+            const void* g = (ty_ < a.H - oh0_f && tx_ < a.W - ow0_f) ? (const void*)(dyb_f + rel) : (const void*)&g_zero16;
+            dma16(g, __builtin_amdgcn_readfirstlane(lds + (C::NW * j + wave) * 1024));
+        } else {
+            const int jj = j - C::NDY;
+            if (C::NW * jj + wave < C::X_PIECES) {             // wave-uniform
+                const int hy = (x_d[jj] >> 8) & 255, hx = x_d[jj] & 255, s_ = (x_d[jj] >> 16) & 15;
+                const int ih = oh0_f - 1 + hy, iw = ow0_f - 1 + hx;
                 const int rel = ((hy * a.W + hx) * a.ldx + s_ * 8) * 2;
-                const bool ok = x_d[j] >= 0 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-                const void* g = ok ? (const void*)(xb + rel) : (const void*)&g_zero16;
-                dma16(g, lds + C::DY_BYTES + (C::NW * j + wave) * 1024);
+                const bool ok = x_d[jj] >= 0 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                const void* g = ok ? (const void*)(xb_f + rel) : (const void*)&g_zero16;
+                dma16(g, __builtin_amdgcn_readfirstlane(lds + C::DY_BYTES + (C::NW * jj + wave) * 1024));
             }
         }
     };
@@ -178,19 +190,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
     // the tile loop is instantiated once per tap-half so each copy has a branch-free, fully unrolled body
     auto tile_loop = [&](auto hf_tag) __attribute__((always_inline)) {
         constexpr int HF = decltype(hf_tag)::value;
-        if (t_begin < t_end) issue_tile(t_begin, 0);
+        if (t_begin < t_end) {
+            set_fetch_tile(t_begin);
+#pragma unroll
+            for (int j = 0; j < C::NDY + C::NX; ++j) issue_piece(j, 0);
+        }
         for (int tile = t_begin; tile < t_end; ++tile) {
             const int buf = (tile - t_begin) & 1;
-            __syncthreads();      // vmcnt(0) + barrier: this tile's DMA has landed for every wave, and every
-                                  // wave is done reading the other buffer
-            if (tile + 1 < t_end) issue_tile(tile + 1, buf ^ 1);
+            dma_wait_all();       // this wave's pieces of the tile have landed ...
+            __syncthreads();      // ... and everyone else's; every wave is also done reading the other buffer
+            const bool more = tile + 1 < t_end;
+            if (more) set_fetch_tile(tile + 1);
+            if (more && !a.dma_interleave) {
+#pragma unroll
+                for (int j = 0; j < C::NDY + C::NX; ++j) issue_piece(j, buf ^ 1);
+            }
             const char* lds = smem + buf * C::BUF;
             if (do_bias) {
                 const int co = tid & 63, part = tid >> 6;
                 for (int r = part; r < C::P; r += 8)
                     bsum += bf16_to_f32(*(const bf16_t*)(lds + r * C::DY_ROW + ((co * 2) ^ (((r >> 1) & 1) << 6))));
             }
-            compute_tile<HF>(lds, a_lane, b_lane, acc);
+            compute_tile<HF>(lds, a_lane, b_lane, acc, [&](int kk) __attribute__((always_inline)) {
+                // 10 pieces over the first three K-steps (4 + 3 + 3)
+                if (more && a.dma_interleave && kk < 3) {
+                    const int j0 = kk == 0 ? 0 : (kk == 1 ? 4 : 7), j1 = kk == 0 ? 4 : (kk == 1 ? 7 : 10);
+#pragma unroll
+                    for (int j = j0; j < j1; ++j) issue_piece(j, buf ^ 1);
+                }
+            });
         }
     };
     if (hf == 0) tile_loop(std::integral_constant<int, 0>{});
@@ -274,6 +302,7 @@ int wgrad_v2_launch(const void* x, int ldx, const void* dy, int lddy, float* sla
     a.ldx = ldx; a.lddy = lddy; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
     a.splits = p.splits; a.co_blocks = p.co_blocks; a.ci_blocks = p.ci_blocks;
+    a.dma_interleave = g_wu_opt[WU_OPT_WGRAD_DMA_INTERLEAVE];
     const int grid = p.splits * p.co_blocks * p.ci_blocks;
     static thread_local bool attr_set = false;
     if (!attr_set) {
