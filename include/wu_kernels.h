@@ -153,11 +153,11 @@ int wu_adain_upcat_fwd(const void* x, int ldx, const float* stats, const float* 
                        void* y, int ldy, int N, int H, int W, int C, float p_drop, uint64_t seed,
                        uint8_t* mask_bits, int dtype, void* stream);
 /* Backward of the above.  dy: gradient of the concat buffer channels [0,C) (N,2H,2W) ld=lddy.
- * Produces dx (N,H,W,C) ld=lddx and d_y_std, d_y_mean (N,C) fp32.  `gtmp` (N*H*W*C floats) and
+ * Produces dx (N,H,W,C) ld=lddx and d_y_std, d_y_mean (N,C) fp32.  `gtmp` (N*H*W*C elements of `dtype`) and
  * `sums` (N*C*2*(1+WU_MAX_SPLITS) floats) are caller-provided scratch.  x_gate_act != 0: dx is additionally multiplied by
  * act'(x) (x is a conv activation output; the producer conv then receives a pre-gated gradient). */
 int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int ldx, const float* stats, const float* y_std,
-                       void* dx, int lddx, float* d_y_std, float* d_y_mean, float* gtmp, float* sums,
+                       void* dx, int lddx, float* d_y_std, float* d_y_mean, void* gtmp, float* sums,
                        int N, int H, int W, int C, float p_drop, uint64_t seed, const uint8_t* mask_bits,
                        int x_gate_act, int dtype, void* stream);
 /* The keep-mask wu_adain_upcat_fwd draws for (seed, p): mask[n][c][h2][w2] (NCHW uint8), for tests. */

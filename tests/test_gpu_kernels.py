@@ -316,7 +316,7 @@ def test_adain_upcat_bwd_mask_bits_vs_rehash(p):
     for mb in (bits.data_ptr(), None):
         dx = empty_nhwc(n, c, h, w, _tdt(p), _dev())
         dstd, dmean = torch.empty((n, c), device=_dev()), torch.empty((n, c), device=_dev())
-        gtmp = torch.empty((n, h, w, c), device=_dev())
+        gtmp = torch.empty((n, h, w, c), dtype=_tdt(p), device=_dev())
         sums = torch.empty((n, c, 2 * (1 + WF.MAX_SPLITS)), device=_dev())
         _lib.call("wu_adain_upcat_bwd", g.data_ptr(), nhwc_ld(g), x.data_ptr(), nhwc_ld(x), stats.data_ptr(), ystd.data_ptr(),
                   dx.data_ptr(), nhwc_ld(dx), dstd.data_ptr(), dmean.data_ptr(), gtmp.data_ptr(), sums.data_ptr(),

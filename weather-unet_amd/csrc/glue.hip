@@ -232,35 +232,52 @@ __global__ __launch_bounds__(256) void adain_upcat_fwd_kernel(const T* __restric
             kb[e] = ym[e] - st[2 * e] * ka[e];
         }
         const T* b = x + (size_t)n * H * W * ldx + ch * E;
+        // all 4 x RPT neighbour loads are issued before any is consumed (rows past the image are clamped and skipped
+        // at the store): one memory round trip per RPT output rows instead of one per row
+        Lerp lys[RPT];
+        uint4 q[RPT][4];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int oh = min(oh_base + r, H2 - 1);
+            lys[r] = src_index(oh, sy, H);
+            q[r][0] = *(const uint4*)(b + (size_t)(lys[r].i0 * W + lx.i0) * ldx);
+            q[r][1] = *(const uint4*)(b + (size_t)(lys[r].i0 * W + lx.i1) * ldx);
+            q[r][2] = *(const uint4*)(b + (size_t)(lys[r].i1 * W + lx.i0) * ldx);
+            q[r][3] = *(const uint4*)(b + (size_t)(lys[r].i1 * W + lx.i1) * ldx);
+        }
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             const int oh = oh_base + r;
-            if (oh >= H2) break;
-            const Lerp ly = src_index(oh, sy, H);
-            float v00[E], v01[E], v10[E], v11[E], o[E];
-            unpack16<T>(*(const uint4*)(b + (size_t)(ly.i0 * W + lx.i0) * ldx), v00);
-            unpack16<T>(*(const uint4*)(b + (size_t)(ly.i0 * W + lx.i1) * ldx), v01);
-            unpack16<T>(*(const uint4*)(b + (size_t)(ly.i1 * W + lx.i0) * ldx), v10);
-            unpack16<T>(*(const uint4*)(b + (size_t)(ly.i1 * W + lx.i1) * ldx), v11);
-            const size_t opix = ((size_t)n * H2 + oh) * W2 + ow;
-            bool keep[E];
-            if (thr < 0x10000u) {
-                keep_bits<E>(seed, (uint64_t)opix * C + ch * E, thr, keep);
-                if (mbits) {        // one byte per 16-B chunk: backward reads the mask instead of re-hashing
-                    uint32_t bits = 0;
+            if (oh < H2) {
+                const Lerp ly = lys[r];
+                float v00[E], v01[E], v10[E], v11[E], o[E];
+                unpack16<T>(q[r][0], v00);
+                unpack16<T>(q[r][1], v01);
+                unpack16<T>(q[r][2], v10);
+                unpack16<T>(q[r][3], v11);
+                const size_t opix = ((size_t)n * H2 + oh) * W2 + ow;
+                bool keep[E];
+                if (thr < 0x10000u) {
+                    keep_bits<E>(seed, (uint64_t)opix * C + ch * E, thr, keep);
+                    if (mbits) {        // one byte per 16-B chunk: backward reads the mask instead of re-hashing
+                        uint32_t bits = 0;
 #pragma unroll
-                    for (int e = 0; e < E; ++e) bits |= (keep[e] ? 1u : 0u) << e;
-                    mbits[opix * cpp + ch] = (uint8_t)bits;
+                        for (int e = 0; e < E; ++e) bits |= (keep[e] ? 1u : 0u) << e;
+                        mbits[opix * cpp + ch] = (uint8_t)bits;
+                    }
                 }
-            }
+                // the kernel is VALU-bound: 4 products with pre-multiplied tap weights (+1 FMA for the AdaIN affine) instead
+                // of the 6-op nested form; the dropout scale is folded into the affine coefficients
+                const float w00 = ly.l0 * lx.l0, w01 = ly.l0 * lx.l1, w10 = ly.l1 * lx.l0, w11 = ly.l1 * lx.l1;
+                const float ds = (thr < 0x10000u) ? keep_scale : 1.f;
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const float v = ly.l0 * (lx.l0 * v00[e] + lx.l1 * v01[e]) + ly.l1 * (lx.l0 * v10[e] + lx.l1 * v11[e]);
-                float rr = v * ka[e] + kb[e];
-                if (thr < 0x10000u) rr = keep[e] ? rr * keep_scale : 0.f;     // nn.Dropout(p) train mode
-                o[e] = rr;
+                for (int e = 0; e < E; ++e) {
+                    const float v = w00 * v00[e] + w01 * v01[e] + w10 * v10[e] + w11 * v11[e];
+                    const float rr = v * (ka[e] * ds) + kb[e] * ds;
+                    o[e] = (thr < 0x10000u && !keep[e]) ? 0.f : rr;               // nn.Dropout(p) train mode
+                }
+                *(uint4*)(y + opix * ldy + ch * E) = pack16<T>(o);
             }
-            *(uint4*)(y + opix * ldy + ch * E) = pack16<T>(o);
         }
     }
 }
@@ -270,7 +287,7 @@ __global__ __launch_bounds__(256) void adain_upcat_fwd_kernel(const T* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void adain_upcat_bwd_gather_kernel(
     const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx, const float* __restrict__ stats,
-    float* __restrict__ gtmp, float* __restrict__ sums, int H, int W, int C,
+    T* __restrict__ gtmp, float* __restrict__ sums, int H, int W, int C,
     float sy, float sx, uint32_t thr, float keep_scale, uint64_t seed, const uint8_t* __restrict__ mbits) {
     constexpr int E = ElemTraits<T>::kPer16B;
     constexpr int LP = 64 / E, PP = 256 / LP;
@@ -352,9 +369,8 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_gather_kernel(
             s1[e] += g[e];
             s2[e] += g[e] * ((xv[e] - st[2 * e]) * st[2 * e + 1]);
         }
-        float* gd = gtmp + ((size_t)n * HW + p) * C + c0;
-#pragma unroll
-        for (int e = 0; e < E; e += 4) *(float4*)(gd + e) = make_float4(g[e], g[e + 1], g[e + 2], g[e + 3]);
+        // g' is parked in the storage dtype (its statistics above were taken in fp32 before rounding)
+        *(uint4*)(gtmp + ((size_t)n * HW + p) * C + c0) = pack16<T>(g);
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -380,7 +396,7 @@ __global__ void fold_partials_kernel(const float* __restrict__ part, float* __re
 // d_y_std = sum g'*xhat.
 // grid: x = 256-thread chunks of one image (HW * C/E items), y = image
 template <typename T>
-__global__ __launch_bounds__(256) void adain_upcat_bwd_apply_kernel(const float* __restrict__ gtmp, const float* __restrict__ sums,
+__global__ __launch_bounds__(256) void adain_upcat_bwd_apply_kernel(const T* __restrict__ gtmp, const float* __restrict__ sums,
                                              const T* __restrict__ x, int ldx, const float* __restrict__ stats,
                                              const float* __restrict__ y_std, T* __restrict__ dx, int lddx,
                                              float* __restrict__ d_y_std, float* __restrict__ d_y_mean,
@@ -395,7 +411,7 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_apply_kernel(const float*
         const int sc = n * C + ch * E;
         float xv[E], o[E], g[E], st[2 * E], sm[2 * E], ys[E];
         unpack16<T>(*(const uint4*)(x + p * ldx + ch * E), xv);
-        ldf<E>(gtmp + p * C + ch * E, g);
+        unpack16<T>(*(const uint4*)(gtmp + p * C + ch * E), g);
         ldf<2 * E>(stats + 2 * sc, st);
         ldf<2 * E>(sums + 2 * sc, sm);
         ldf<E>(y_std + sc, ys);
@@ -613,7 +629,7 @@ extern "C" int wu_adain_upcat_fwd(const void* x, int ldx, const float* stats, co
 }
 
 extern "C" int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int ldx, const float* stats, const float* y_std,
-                                  void* dx, int lddx, float* d_y_std, float* d_y_mean, float* gtmp, float* sums,
+                                  void* dx, int lddx, float* d_y_std, float* d_y_mean, void* gtmp, float* sums,
                                   int N, int H, int W, int C, float p_drop, uint64_t seed, const uint8_t* mask_bits,
                                   int x_gate_act, int dtype, void* stream) {
     const int esz = dtype == WU_BF16 ? 2 : 4;
@@ -632,9 +648,9 @@ extern "C" int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int l
     float* partials = sums + (size_t)N * C * 2;
     DISPATCH_T(dtype, {
         hipLaunchKernelGGL(adain_upcat_bwd_gather_kernel<T>, dim3(C / 64, splits, N), dim3(256), 0, s, (const T*)dy, lddy, (const T*)x, ldx,
-                           stats, gtmp, partials, H, W, C, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), seed, mask_bits);
+                           stats, (T*)gtmp, partials, H, W, C, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), seed, mask_bits);
         hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(N * C * 2, 256)), dim3(256), 0, s, partials, sums, N * C * 2, splits);
-        hipLaunchKernelGGL(adain_upcat_bwd_apply_kernel<T>, dim3(grid_for((long long)HW * (C / (16 / esz)), 256, 1024), N), dim3(256), 0, s, gtmp, sums, (const T*)x, ldx, stats, y_std,
+        hipLaunchKernelGGL(adain_upcat_bwd_apply_kernel<T>, dim3(grid_for((long long)HW * (C / (16 / esz)), 256, 1024), N), dim3(256), 0, s, (const T*)gtmp, sums, (const T*)x, ldx, stats, y_std,
                            (T*)dx, lddx, d_y_std, d_y_mean, N, HW, C, x_gate_act);
     });
     WU_LAUNCH_CHECK("adain_upcat_bwd");

@@ -62,6 +62,63 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(const float* __rest
     }
 }
 
+// NHWC-output form of the conv above (Cout = 64), production path.  One thread = one output pixel with its 27 inputs in
+// registers; the output channels are walked in the OUTER loop, so the weights w[co][0..26] are wave-uniform and come
+// through the scalar cache (s_load) straight into the FMAs: no LDS weight traffic (the LDS-broadcast form above spends
+// 432 ds_read_b128 per pixel).  Results are packed 8 channels at a time into an LDS tile [256 px][64 ch] (144-B rows) and
+// copied out with 16-B stores that cover 1 KiB contiguous per wave instruction.
+template <typename T, int STRIDE, int ACT>
+__global__ __launch_bounds__(256) void conv3x3_c3_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, const float* __restrict__ inv_sigma,
+                                                                  T* __restrict__ y, int ldy, int N, int H, int W) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    constexpr int ROW = 64 * (int)sizeof(T) + 16;
+    __shared__ __attribute__((aligned(16))) char tile[256 * ROW];
+    const float s = inv_sigma ? *inv_sigma : 1.f;
+    const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
+    const long long total = (long long)N * Ho * Wo;
+    const long long nblk = (total + 255) / 256;
+    for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const long long pix = blk * 256 + threadIdx.x;
+        float xv[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) xv[k] = 0.f;
+        if (pix < total) {
+            const int ow = (int)(pix % Wo), oh = (int)((pix / Wo) % Ho), n = (int)(pix / ((long long)Wo * Ho));
+            const float* xn = x + (size_t)n * 3 * H * W;
+#pragma unroll
+            for (int k = 0; k < 27; ++k) {
+                const int ci = k / 9, t = k % 9, ih = oh * STRIDE + t / 3 - 1, iw = ow * STRIDE + t % 3 - 1;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W) xv[k] = xn[((size_t)ci * H + ih) * W + iw];
+            }
+        }
+#pragma unroll 1
+        for (int cg = 0; cg < 64 / E; ++cg) {
+            float o[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int co = cg * E + e;                       // wave-uniform: scalar loads
+                const float* wr = w + co * 27;
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 27; ++k) a += xv[k] * wr[k];
+                o[e] = act_apply(a * s + (bias ? bias[co] : 0.f), ACT);
+            }
+            *(uint4*)(tile + threadIdx.x * ROW + cg * 16) = pack16<T>(o);
+        }
+        __syncthreads();
+        constexpr int SLOTS = 64 * (int)sizeof(T) / 16;
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            const int q = threadIdx.x + 256 * k;
+            const int r = q / SLOTS, sl = q % SLOTS;
+            const long long p2 = blk * 256 + r;
+            if (p2 < total) *(uint4*)(y + (size_t)p2 * ldy + sl * E) = *(const uint4*)(tile + r * ROW + sl * 16);
+        }
+        __syncthreads();
+    }
+}
+
 // weight/bias gradient: dW[co][k] += sum_pix dy'[pix][co] * patch[pix][k], k = ci*9+tap (27).
 // Workgroup = 64 couts x 4 k-groups; pixels staged through LDS in batches of 64.
 template <typename T, int STRIDE, bool DY_NCHW>
@@ -519,9 +576,19 @@ extern "C" int wu_conv3x3_c3_fwd(const float* x_nchw, const float* w_oihw, const
     const int grid = grid_cap((long long)N * Ho * Wo, 256, 256 * 32);
 #define C3_LAUNCH_A(T, CO, ST, NCHW, A) hipLaunchKernelGGL((conv3x3_c3_fwd_kernel<T, CO, ST, NCHW, A>), dim3(grid), dim3(256), 0, s, x_nchw, w_oihw, bias, inv_sigma, y, ldy, N, H, W)
 #define C3_LAUNCH(T, CO, ST, NCHW) do { if (act == WU_ACT_RELU) C3_LAUNCH_A(T, CO, ST, NCHW, WU_ACT_RELU); else if (act == WU_ACT_LEAKY) C3_LAUNCH_A(T, CO, ST, NCHW, WU_ACT_LEAKY); else C3_LAUNCH_A(T, CO, ST, NCHW, WU_ACT_NONE); } while (0)
+#define C3_LANES_A(T, ST, A) hipLaunchKernelGGL((conv3x3_c3_fwd_rows_kernel<T, ST, A>), dim3(grid_l), dim3(256), 0, s, x_nchw, w_oihw, bias, inv_sigma, (T*)y, ldy, N, H, W)
+#define C3_LANES(T, ST) do { if (act == WU_ACT_RELU) C3_LANES_A(T, ST, WU_ACT_RELU); else if (act == WU_ACT_LEAKY) C3_LANES_A(T, ST, WU_ACT_LEAKY); else C3_LANES_A(T, ST, WU_ACT_NONE); } while (0)
+    const int grid_l = grid_cap((long long)N * Ho * Wo, 256, 256 * 8);
+    // the LDS-broadcast one-thread-per-pixel kernel measured fastest (239 us at B=32 256x256); the scalar-weight /
+    // transposed-store variant (conv3x3_c3_fwd_rows_kernel, 326 us) is kept selectable for A/B work
     if (out_nchw) C3_LAUNCH(float, 3, 1, true);
-    else if (dtype == WU_BF16) { if (stride == 1) C3_LAUNCH(bf16_t, 64, 1, false); else C3_LAUNCH(bf16_t, 64, 2, false); }
+    else if (g_wu_opt[WU_OPT_C3_ROWS]) {
+        if (dtype == WU_BF16) { if (stride == 1) C3_LANES(bf16_t, 1); else C3_LANES(bf16_t, 2); }
+        else { if (stride == 1) C3_LANES(float, 1); else C3_LANES(float, 2); }
+    } else if (dtype == WU_BF16) { if (stride == 1) C3_LAUNCH(bf16_t, 64, 1, false); else C3_LAUNCH(bf16_t, 64, 2, false); }
     else { if (stride == 1) C3_LAUNCH(float, 64, 1, false); else C3_LAUNCH(float, 64, 2, false); }
+#undef C3_LANES
+#undef C3_LANES_A
 #undef C3_LAUNCH_A
 #undef C3_LAUNCH
     WU_LAUNCH_CHECK("conv3x3_c3_fwd");

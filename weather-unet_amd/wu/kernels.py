@@ -151,7 +151,7 @@ def adain_upcat_bwd(g_cat, x, stats, y_std, dx, p_drop, seed, mbits, x_gate_act=
     n, c, h, w = x.shape
     d_std = torch.empty((n, c), dtype=torch.float32, device=x.device)
     d_mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
-    gtmp = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    gtmp = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
     sums = torch.empty((n, c, 2 * (1 + MAX_SPLITS)), dtype=torch.float32, device=x.device)
     _lib.call("wu_adain_upcat_bwd", g_cat.data_ptr(), nhwc_ld(g_cat), x.data_ptr(), nhwc_ld(x), stats.data_ptr(), y_std.data_ptr(),
               dx.data_ptr(), nhwc_ld(dx), d_std.data_ptr(), d_mean.data_ptr(), gtmp.data_ptr(), sums.data_ptr(),
