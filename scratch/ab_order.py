@@ -20,8 +20,8 @@ for name, ci, co, s in layers:
     res = {0: [], 1: []}; outs = {}
     for rnd in range(7):
         for order in (0, 1):
-            _lib.call('wu_set_option', 3, order)
+            _lib.call('wu_set_option', 6, order)
             res[order].append(run(lambda: K.conv3x3(x, wf, bias, y, 1, 1)))
             if rnd == 0: outs[order] = y.clone()
-    print(f"{name:8s} {ci:4d}->{co:4d} @{s:3d}: ct-fastest {statistics.median(res[0]):7.1f} us ({gf/statistics.median(res[0]):.3f} PF)   ct-slowest {statistics.median(res[1]):7.1f} us ({gf/statistics.median(res[1]):.3f} PF)  equal {torch.equal(outs[0], outs[1])}")
-_lib.call('wu_set_option', 3, 0)
+    print(f"{name:8s} {ci:4d}->{co:4d} @{s:3d}: prio-off {statistics.median(res[0]):7.1f} us ({gf/statistics.median(res[0]):.3f} PF)   prio-waves4-7 {statistics.median(res[1]):7.1f} us ({gf/statistics.median(res[1]):.3f} PF)  equal {torch.equal(outs[0], outs[1])}")
+_lib.call('wu_set_option', 6, 0)

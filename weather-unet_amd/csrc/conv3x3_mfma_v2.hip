@@ -37,7 +37,7 @@ struct V2Args {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; const bf16_t* egate;
     int ldx, ldy, ldegate, egate_act;
     int N, H, W, Cin, Cout, act;
-    int tiles_x, tiles_y, cout_tiles, ntiles, ct_slowest;
+    int tiles_x, tiles_y, cout_tiles, ntiles, ct_slowest, prio_mode;
     unsigned long long* dbg;     // diagnostic: per-workgroup phase cycle sums (NULL in production)
 };
 
@@ -140,6 +140,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a)
     unsigned long long t_wait = 0, t_comp = 0, t_epi_b1 = 0, t_epi_w = 0, t_epi_b2 = 0, t_epi_s = 0, t_mark = 0;
 #define WU_STAMP(acc_var) do { if (a.dbg) { const unsigned long long t_ = __builtin_readcyclecounter(); acc_var += t_ - t_mark; t_mark = t_; } } while (0)
     if (a.dbg) t_mark = __builtin_readcyclecounter();
+    // experiment (A/B switch): static priority for the later-dispatched half of the workgroup (cdna guide T5 static form)
+    if (a.prio_mode == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int nchunks = a.Cin / 32;
     int buf = 0;                                  // LDS buffer holding the chunk being computed
     int stores_in_flight = 0;                     // 8 after an epilogue whose 8 store instructions all issued
@@ -296,6 +298,7 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     a.tiles_x = cdiv(W, K::TW); a.tiles_y = cdiv(H, K::TH); a.cout_tiles = Cout / 64;
     a.dbg = (unsigned long long*)g_wu_dbg_ptr;
     a.ct_slowest = g_wu_opt[WU_OPT_CONV_CT_SLOWEST];
+    a.prio_mode = g_wu_opt[WU_OPT_CONV_PRIO];
     const long long ntiles = (long long)N * a.tiles_x * a.tiles_y * a.cout_tiles;
     if (ntiles >= (1ll << 31)) return -1;
     a.ntiles = (int)ntiles;
