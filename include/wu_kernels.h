@@ -57,6 +57,17 @@ int wu_set_debug_buffer(void* p);
 int wu_pack_conv3x3(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin,
                     const float* inv_sigma, int dtype, void* stream);
 
+/* Spectral normalisation of a conv weight (torch.nn.utils.spectral_norm around the convs of nets.py:28-31):
+ * one power iteration (power_iter != 0: v <- normalize(W^T u), u <- normalize(W v), buffers updated in place),
+ * sigma = u . (W v); sigma_out[0] = sigma, sigma_out[1] = 1/sigma; w_eff (may be NULL) = W / sigma.  W is the OIHW
+ * fp32 weight viewed as rows = Cout, cols = Cin*9.  Backward: dw = g/sigma - (<g,w>/sigma^2) u v^T with u, v the
+ * buffers the forward used (constants of the graph, as in torch).  scratch: wu_spectral_norm_scratch_floats(). */
+size_t wu_spectral_norm_scratch_floats(int rows, int cols);
+int wu_spectral_norm_fwd(const float* w, int rows, int cols, float* u, float* v, int power_iter, float eps,
+                         float* sigma_out, float* w_eff, float* scratch, void* stream);
+int wu_spectral_norm_bwd(const float* g, const float* w, const float* u, const float* v, const float* sigma,
+                         float* dw, int rows, int cols, float* scratch, void* stream);
+
 /* ---- conv3x3, pad 1, MFMA implicit GEMM -----------------------------------------------------
  * y = act(conv3x3(x, w) + bias)   replaces nn.Conv2d(cin,cout,3,padding=1[,stride=2]) + ReLU /
  * LeakyReLU of nets.py:18-33.  x: (N,H,W,Cin) ld=ldx; y: (N,Ho,Wo,Cout) ld=ldy with

@@ -38,8 +38,9 @@ def _worker(rank, world, port, q):
             loss.backward()
             log_before_finalize = list(red.launch_log)
             red.finalize()
-        grads = [p.grad.clone() for p in m.parameters()]
-        w0 = [p.detach().clone() for p in m.parameters()]
+        # numpy arrays are pickled by value (tensors would travel as shared-memory fds that die with this process)
+        grads = [p.grad.detach().numpy().copy() for p in m.parameters()]
+        w0 = [p.detach().numpy().copy() for p in m.parameters()]
         q.put((rank, grads, w0, log_before_finalize, list(red.launch_log), len(red.buckets)))
     finally:
         dist.destroy_process_group()
@@ -58,10 +59,12 @@ def test_bucketed_allreduce_world2():
         assert p.exitcode == 0
     (_, g0, w0, log0, full0, nb), (_, g1, w1, log1, full1, _) = res
     # identical replicas (rank-0 weights) and identical averaged gradients
+    import numpy as np
     for a, b in zip(w0, w1):
-        assert torch.equal(a, b)
+        assert np.array_equal(a, b)
     for a, b in zip(g0, g1):
-        assert torch.equal(a, b)
+        assert np.array_equal(a, b)
+    g0 = [torch.from_numpy(g) for g in g0]
     # single-process reference on the full batch with rank 0's weights
     m = _toy(seed=0)
     torch.manual_seed(123)

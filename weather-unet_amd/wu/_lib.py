@@ -28,6 +28,9 @@ SIGNATURES = {
     "wu_version": (I, []),
     "wu_set_option": (I, [I, I]),
     "wu_set_debug_buffer": (I, [P]),
+    "wu_spectral_norm_scratch_floats": (SZ, [I, I]),
+    "wu_spectral_norm_fwd": (I, [P, I, I, P, P, I, F, P, P, P, P]),
+    "wu_spectral_norm_bwd": (I, [P, P, P, P, P, P, I, I, P, P]),
     "wu_pack_conv3x3": (I, [P, P, P, I, I, P, I, P]),
     "wu_conv3x3_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P, I, I, P, I, I, I, P]),
     "wu_conv3x3_wgrad_workspace": (SZ, [I, I, I, I, I, I, I]),

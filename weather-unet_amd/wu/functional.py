@@ -321,3 +321,45 @@ def adain_apply(x, y_std, y_mean, eps):
     x_mean = flat.mean(dim=-1).view(n, c, 1, 1)
     out = (xf - x_mean) / x_std * y_std.view(n, c, 1, 1) + y_mean.view(n, c, 1, 1)
     return out.to(x.dtype).contiguous(memory_format=torch.channels_last)
+
+
+# ----------------------------------------------------------------------------------------------
+# spectral normalisation of a conv weight      nets.py:28-31 (torch.nn.utils.spectral_norm)
+# ----------------------------------------------------------------------------------------------
+class SpectralNormFn(Function):
+    """W_eff = W_orig / sigma with one power iteration in training mode (u, v updated IN PLACE, like torch's
+    hook).  4 kernel launches forward, 2 backward, instead of ~25 tiny torch kernels per layer and forward."""
+
+    @staticmethod
+    def forward(ctx, weight_orig, u, v, do_power_iteration, eps):
+        require_cuda(weight_orig, "spectral_norm")
+        w = weight_orig.detach()
+        if not w.is_contiguous():
+            w = w.contiguous()
+        rows = w.shape[0]
+        cols = w.numel() // rows
+        lib = _lib.load()
+        scratch = torch.empty(lib.wu_spectral_norm_scratch_floats(rows, cols), dtype=torch.float32, device=w.device)
+        sigma = torch.empty(2, dtype=torch.float32, device=w.device)
+        w_eff = torch.empty_like(w)
+        _lib.call("wu_spectral_norm_fwd", w.data_ptr(), rows, cols, u.data_ptr(), v.data_ptr(), 1 if do_power_iteration else 0,
+                  float(eps), sigma.data_ptr(), w_eff.data_ptr(), scratch.data_ptr(), stream_ptr())
+        # backward needs the u, v that defined sigma: clone (the buffers advance again on the next forward)
+        ctx.save_for_backward(w, u.clone(), v.clone(), sigma)
+        return w_eff
+
+    @staticmethod
+    def backward(ctx, g):
+        w, u, v, sigma = ctx.saved_tensors
+        g = g.float().contiguous()
+        rows = w.shape[0]
+        cols = w.numel() // rows
+        dw = torch.empty_like(w)
+        scratch = torch.empty(_lib.load().wu_spectral_norm_scratch_floats(rows, cols), dtype=torch.float32, device=w.device)
+        _lib.call("wu_spectral_norm_bwd", g.data_ptr(), w.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(),
+                  dw.data_ptr(), rows, cols, scratch.data_ptr(), stream_ptr())
+        return dw, None, None, None, None
+
+
+def spectral_normalize(weight_orig, u, v, do_power_iteration, eps=1e-12):
+    return SpectralNormFn.apply(weight_orig, u, v, do_power_iteration, eps)
