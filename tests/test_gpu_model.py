@@ -383,3 +383,54 @@ def test_checkpoint_interchange_and_class_sweep(tmp_path):
     assert torch.equal(class_sweep(g2, xd, graphed=GraphedUNet(g2, 2, 64)), sweep)
     nm = normalize_minmax(sweep[0])
     assert nm.min().item() >= 0 and abs(nm.reshape(2, -1).max(dim=1).values - 1).max().item() < 1e-3
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] size (256x256, B=32, bf16), where the CPU oracle would take minutes: size-independent
+    properties instead.  (a) run-to-run determinism of forward AND every parameter gradient (deterministic split-K,
+    fixed-order reductions, seeded dropout); (b) batch independence: an image's output does not depend on what else is
+    in the batch (to bf16 rounding); (c) the bf16 production kernels (LDS-DMA conv / wgrad) against the fp32 generic kernels on
+    the same weights at full resolution: forward within the bf16 tolerance, gradients aligned."""
+    nc = 5
+    torch.manual_seed(3)
+    net = _make_g(nc, 2, "bf16").train()
+    net.dropout_seed = 5
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand((32, 3, 256, 256), generator=g) * 2 - 1).to(DEV)
+    c = torch.eye(nc)[torch.arange(32) % nc].to(DEV)
+
+    def run(model, xx, cc):
+        for p in model.parameters():
+            p.grad = None
+        out = model(xx, cc)
+        torch.mean(torch.abs(out - xx)).backward()
+        return out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    o1, g1 = run(net, x, c)
+    o2, g2 = run(net, x, c)
+    assert torch.equal(o1, o2)
+    for k in g1:
+        if k.startswith(("dconv_down1.0", "conv_last")):
+            # the two thin layers reduce their (tiny) weight gradients with fp32 atomics: order-dependent last bits
+            assert torch.allclose(g1[k], g2[k], rtol=1e-4, atol=1e-7), f"gradient of {k}"
+        else:
+            assert torch.equal(g1[k], g2[k]), f"gradient of {k} is not reproducible"
+    # (b) eval mode: images 6..7 alone == images 6..7 inside the batch of 32
+    net.eval()
+    with torch.no_grad():
+        full = net(x, c)
+        part = net(x[6:8].contiguous(), c[6:8].contiguous())
+    # not bitwise: the instance-norm statistics split their H*W reduction by a factor chosen from N*C (to fill the chip), so the
+    # fp32 summation order -- and hence an occasional bf16 rounding downstream -- depends on the batch size
+    assert (full[6:8] - part).abs().max().item() <= 2e-2
+    assert (full[6:8] - part).abs().mean().item() <= 1e-3
+    # (c) fp32 generic kernels vs bf16 production kernels, B=4 at 256x256
+    net32 = _make_g(nc, 2, "fp32").eval()
+    xs, cs = x[:4].contiguous(), c[:4].contiguous()
+    o32, g32 = run(net32, xs, cs)
+    o16, g16 = run(net, xs, cs)
+    assert (o32 - o16).abs().max().item() <= FWD_TOL["bf16"]
+    for k in ("dconv_up1.2.weight", "dconv_up1.0.weight", "dconv_up3.0.weight", "dconv_down4.2.weight", "conv_last.weight"):
+        a, b = g16[k].double().reshape(-1), g32[k].double().reshape(-1)
+        cos = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
+        assert cos >= 0.97, f"{k}: cosine {cos}"
