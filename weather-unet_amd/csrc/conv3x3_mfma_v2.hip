@@ -28,9 +28,15 @@ struct K {
     static constexpr int W_PIECES = 9 * 64 * 64 / 1024;              // 36
     static constexpr int W_BYTES = W_PIECES * 1024;
     static constexpr int BUF = H_BYTES + W_BYTES;                    // 76800 B, two buffers = 150 KiB
-    static constexpr int NW = 8;
-    static constexpr int NH = (H_PIECES + NW - 1) / NW;              // 5 halo pieces per wave
-    static constexpr int NWT = (W_PIECES + NW - 1) / NW;             // 5 weight pieces per wave
+};
+// NW waves share the tile: 8 (two per SIMD, 2 tile rows = 4 accumulators each) or 4 (one per SIMD, 4 rows = 8 accumulators)
+template <int NW_> struct KW {
+    static constexpr int NW = NW_;
+    static constexpr int RPW = K::TH / NW;                               // tile rows per wave
+    static constexpr int NH = (K::H_PIECES + NW - 1) / NW;               // halo pieces per wave
+    static constexpr int NWT = (K::W_PIECES + NW - 1) / NW;              // weight pieces per wave
+    static constexpr int NP = NH + NWT;
+    static constexpr int NST = K::P * 8 / (NW * 64);                     // 16-B output stores per thread and tile
 };
 
 struct V2Args {
@@ -54,7 +60,9 @@ __device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& 
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a) {
+    using Q = KW<NW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,26 +76,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a)
 
     // ---- tile-invariant parts of the DMA descriptors: LDS slot i = piece*64 + lane ----
     // halo: pixel p = i >> 2, LDS 16-B slot sl = i & 3 holds channel slot sl ^ swz(hx); packed (hy << 8 | hx | s << 16), -1 = never valid
-    int hdesc[K::NH];
+    int hdesc[Q::NH];
 #pragma unroll
-    for (int j = 0; j < K::NH; ++j) {
-        const int i = (K::NW * j + wave) * 64 + lane;
+    for (int j = 0; j < Q::NH; ++j) {
+        const int i = (NW * j + wave) * 64 + lane;
         const int p = i >> 2, sl = i & 3;
         const int hy = p / K::HALO_W, hx = p - hy * K::HALO_W;
         hdesc[j] = (p < K::HALO_PIX) ? ((hy << 8) | hx | ((sl ^ ((hx >> 2) & 3)) << 16)) : -1;
     }
     // weights: row = i >> 2 = tap*64 + co, slot sl holds channel slot sl ^ swz(co): element offset relative to cout tile 0
-    int wrel[K::NWT];
+    int wrel[Q::NWT];
 #pragma unroll
-    for (int j = 0; j < K::NWT; ++j) {
-        const int i = (K::NW * j + wave) * 64 + lane;
+    for (int j = 0; j < Q::NWT; ++j) {
+        const int i = (NW * j + wave) * 64 + lane;
         const int row = i >> 2, sl = i & 3;
         const int tap = row >> 6, co = row & 63;
         wrel[j] = (tap * a.Cout + co) * a.Cin + (sl ^ ((co >> 2) & 3)) * 8;     // < 9*512*768 elements: fits int32
     }
 
     // descriptors of the tile whose chunks are currently being FETCHED (one tile ahead at tile boundaries)
-    int hsrc[K::NH];
+    int hsrc[Q::NH];
     const bf16_t* xin_f = nullptr;
     const bf16_t* w_f = nullptr;
     auto set_fetch_tile = [&](int tile) __attribute__((always_inline)) {
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a)
         xin_f = a.x + (size_t)n * a.H * a.W * a.ldx;
         w_f = a.w + (size_t)ct * 64 * a.Cin;
 #pragma unroll
-        for (int j = 0; j < K::NH; ++j) {
+        for (int j = 0; j < Q::NH; ++j) {
             const int hy = (hdesc[j] >> 8) & 255, hx = hdesc[j] & 255, s_ = (hdesc[j] >> 16) & 3;
             const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
             hsrc[j] = (hdesc[j] >= 0 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) ? (ih * a.W + iw) * a.ldx + s_ * 8 : -1;
@@ -112,65 +120,59 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a)
     auto issue_piece = [&](int j, int c0, int buf) __attribute__((always_inline)) {
         const unsigned lds = smem_base + buf * K::BUF;
         // j in [0, NH): halo piece; j in [NH, NH + NWT): weight piece (wave-uniform guards)
-        if (j < K::NH) {
-            if (K::NW * j + wave < K::H_PIECES) {
+        if (j < Q::NH) {
+            if (NW * j + wave < K::H_PIECES) {
                 const void* g = hsrc[j] >= 0 ? (const void*)(xin_f + hsrc[j] + c0) : (const void*)&g_zero16v2;
-                dma16(g, __builtin_amdgcn_readfirstlane(lds + (K::NW * j + wave) * 1024));
+                dma16(g, __builtin_amdgcn_readfirstlane(lds + (NW * j + wave) * 1024));
             }
         } else {
-            const int jj = j - K::NH;
-            if (K::NW * jj + wave < K::W_PIECES)
-                dma16((const void*)(w_f + wrel[jj] + c0), __builtin_amdgcn_readfirstlane(lds + K::H_BYTES + (K::NW * jj + wave) * 1024));
+            const int jj = j - Q::NH;
+            if (NW * jj + wave < K::W_PIECES)
+                dma16((const void*)(w_f + wrel[jj] + c0), __builtin_amdgcn_readfirstlane(lds + K::H_BYTES + (NW * jj + wave) * 1024));
         }
     };
 
     // ---- per-lane fragment bases ----
-    // A: wave owns tile rows 2*wave + mi; lane row l31 = tx; 16-B slot = 2*ks + lh, swizzled with ((tx + kw) >> 2) & 3
+    // A: wave owns tile rows RPW*wave + mi; lane row l31 = tx; 16-B slot = 2*ks + lh, swizzled with ((tx + kw) >> 2) & 3
     int a_lane[3][2];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            a_lane[kw][ks] = ((2 * wave) * K::HALO_W + l31) * 64 + (((2 * ks + lh) ^ (((l31 + kw) >> 2) & 3)) << 4);
+            a_lane[kw][ks] = ((Q::RPW * wave) * K::HALO_W + l31) * 64 + (((2 * ks + lh) ^ (((l31 + kw) >> 2) & 3)) << 4);
     // B: cout row 32*ni + l31 (swizzle depends on l31 only), slot 2*ks + lh
     int b_lane[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) b_lane[ks] = K::H_BYTES + l31 * 64 + (((2 * ks + lh) ^ ((l31 >> 2) & 3)) << 4);
 
-    unsigned long long t_wait = 0, t_comp = 0, t_epi_b1 = 0, t_epi_w = 0, t_epi_b2 = 0, t_epi_s = 0, t_mark = 0;
+    unsigned long long t_wait = 0, t_comp = 0, t_epi_b1 = 0, t_epi_b2 = 0, t_epi_s = 0, t_mark = 0;
 #define WU_STAMP(acc_var) do { if (a.dbg) { const unsigned long long t_ = __builtin_readcyclecounter(); acc_var += t_ - t_mark; t_mark = t_; } } while (0)
-    if (a.dbg) t_mark = __builtin_readcyclecounter();
+    unsigned long long t_k0 = 0, t_r0 = 0;
+    if (a.dbg) { t_mark = __builtin_readcyclecounter(); t_k0 = t_mark; t_r0 = __builtin_amdgcn_s_memrealtime(); }
     // experiment (A/B switch): static priority for the later-dispatched half of the workgroup (cdna guide T5 static form)
-    if (a.prio_mode == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (NW == 8 && a.prio_mode == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int nchunks = a.Cin / 32;
     int buf = 0;                                  // LDS buffer holding the chunk being computed
-    int stores_in_flight = 0;                     // 8 after an epilogue whose 8 store instructions all issued
+    bool stores_in_flight = false;                // true after an epilogue whose NST store instructions all issued
     set_fetch_tile(t_begin);
 #pragma unroll
-    for (int j = 0; j < K::NH + K::NWT; ++j) issue_piece(j, 0, 0);
+    for (int j = 0; j < Q::NP; ++j) issue_piece(j, 0, 0);
 
     for (int tile = t_begin; tile < t_end; ++tile) {
         // accumulators are kept TRANSPOSED (rows = cout, cols = pixels: the weight fragment is the MFMA A operand):
         // a lane then owns 4 consecutive channels of one pixel per register quad -> 8-byte epilogue writes
-        f32x16_t acc[2][2];
+        f32x16_t acc[Q::RPW][2];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < Q::RPW; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
-        // bias of this tile's 64 channels, in the transposed-accumulator layout (4 consecutive channels per register
-        // quad): requested HERE so the loads complete under the MFMAs instead of stalling the epilogue
+        // bias of this tile's 64 channels, in the transposed-accumulator layout (4 consecutive channels per register quad).
+        // Requested right AFTER chunk 0's wait (below), not here: a load issued between the previous epilogue's stores and
+        // that wait would be the youngest vector-memory op and make the counted vmcnt wait drain the stores.
         float4 bvq[2][4];
-        {
-            const int ct_ = a.ct_slowest ? tile / (a.ntiles / a.cout_tiles) : tile % a.cout_tiles;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    bvq[ni][g] = a.bias ? *(const float4*)(a.bias + ct_ * 64 + 32 * ni + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
         for (int c = 0; c < nchunks; ++c) {
             const char* lds = smem + buf * K::BUF;
             const int nxt = buf ^ 1;
@@ -181,39 +183,47 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a)
             // this wave's pieces of the current chunk must have landed.  Right after an interior tile's epilogue the 8
             // output stores are the YOUNGEST vector-memory ops and every DMA piece is older: vmcnt(8) retires the DMA
             // without draining the stores to HBM (vmcnt counts loads, stores and LDS-DMA together, in issue order).
-            if (stores_in_flight == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (stores_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q::NST) : "memory");
             else dma_wait_all();
-            stores_in_flight = 0;
+            stores_in_flight = false;
             WU_STAMP(t_wait);
             __syncthreads();     // ... and so have everyone else's; everyone is also done with the other buffer
             WU_STAMP(t_epi_b2);  // (diagnostic) chunk-top barrier time is folded into the 'barrier2' slot
+            if (c == 0) {
+                const int ct_ = a.ct_slowest ? tile / (a.ntiles / a.cout_tiles) : tile % a.cout_tiles;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        bvq[ni][g] = a.bias ? *(const float4*)(a.bias + ct_ * 64 + 32 * ni + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             if (last && more) set_fetch_tile(tile + 1);
             // 18 steps (tap, ks), software-pipelined by hand: the fragments of step s+1 are requested BEFORE the four
             // MFMAs of step s are issued, so one LDS round trip is always covered by matrix work of this wave
             // (a 2-step look-ahead measured 2-3 % slower).
-            auto load_step = [&](int step, uint4 (&af)[2], uint4 (&bf)[2]) __attribute__((always_inline)) {
+            auto load_step = [&](int step, uint4 (&af)[Q::RPW], uint4 (&bf)[2]) __attribute__((always_inline)) {
                 const int tap = step >> 1, ks = step & 1, kh = tap / 3, kw = tap % 3;
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < Q::RPW; ++mi)
                     af[mi] = *(const uint4*)(lds + a_lane[kw][ks] + ((mi + kh) * K::HALO_W + kw) * 64);
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     bf[ni] = *(const uint4*)(lds + b_lane[ks] + (tap * 64 + 32 * ni) * 64);
             };
-            uint4 af[2][2], bf[2][2];
+            uint4 af[2][Q::RPW], bf[2][2];
             load_step(0, af[0], bf[0]);
 #pragma unroll
             for (int step = 0; step < 18; ++step) {
                 const int cur = step & 1;
                 if (step + 1 < 18) load_step(step + 1, af[cur ^ 1], bf[cur ^ 1]);
-                // issue the next chunk's 10 DMA pieces at the START of this chunk (2 per step, steps 0..4): their address
+                // issue the next chunk's DMA pieces (10 per wave at NW=8, 19 at NW=4) at the START of this chunk (2 per step): their address
                 // VALU work hides behind MFMAs and they get ~3/4 of the chunk to land (LDS-DMA latency ~1.2 us)
-                if (more && step <= 4) {
+                if (more && 2 * step < Q::NP) {
                     issue_piece(2 * step, c1, nxt);
-                    issue_piece(2 * step + 1, c1, nxt);
+                    if (2 * step + 1 < Q::NP) issue_piece(2 * step + 1, c1, nxt);
                 }
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < Q::RPW; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) mma(acc[mi][ni], bf[cur][ni], af[cur][mi]);   // D^T = W * X^T
             }
@@ -230,55 +240,56 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_v2_kernel(const V2Args a)
         const int ty = tt % a.tiles_y;
         const int n = tt / a.tiles_y;
         const int oh0 = ty * K::TH, ow0 = tx * K::TW, co0 = ct * 64;
-        char* epi = smem + (buf ^ 1) * K::BUF;
-        constexpr int kRow = 64 * 2 + 16;
-        __syncthreads();         // every wave is done reading the last chunk
+        // Direct epilogue, no LDS and no workgroup barrier: bias + activation in fp32, bf16 packing, then one
+        // v_permlane32_swap per dword pairs the two half-waves' 8-byte channel groups into 16 contiguous bytes per lane
+        // (lanes 0-31: channels 8k..8k+7 of their pixel, lanes 32-63: 8k+8..8k+15) -> 16-byte stores straight from registers.
+        // A wave that finishes its MFMAs early does this while its SIMD partner still computes.
         WU_STAMP(t_epi_b1);
-        // the activation is selected ONCE per tile (a per-element runtime switch costs a scalar branch per value)
-        auto epi_write = [&](auto act_tag) __attribute__((always_inline)) {
+        const size_t img_pix = (size_t)n * a.H * a.W;
+        auto epi_store = [&](auto act_tag) __attribute__((always_inline)) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int mi = 0; mi < Q::RPW; ++mi) {
+                const int oh = oh0 + Q::RPW * wave + mi, ow = ow0 + l31;
+                const bool ok = oh < a.H && ow < a.W;
+                const size_t pix = img_pix + (size_t)(oh * a.W + ow);
+                bf16_t* yp = a.y + pix * a.ldy + co0 + 8 * lh;
+                const bf16_t* ep = a.egate ? a.egate + pix * a.ldegate + co0 + 8 * lh : nullptr;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    // registers 4g..4g+3 = channels 32*ni + 8g + 4*lh + (0..3) of pixel column l31
-                    const int cb = 32 * ni + 8 * g + 4 * lh;
-                    const float4 bv = bvq[ni][g];
+                for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) {
-                        const int row = (2 * wave + mi) * 32 + l31;
-                        const uint32_t lo = pack_bf16x2(act_apply(acc[mi][ni][4 * g + 0] + bv.x, ACT), act_apply(acc[mi][ni][4 * g + 1] + bv.y, ACT));
-                        const uint32_t hi = pack_bf16x2(act_apply(acc[mi][ni][4 * g + 2] + bv.z, ACT), act_apply(acc[mi][ni][4 * g + 3] + bv.w, ACT));
-                        *(uint2*)(epi + row * kRow + cb * 2) = make_uint2(lo, hi);
+                    for (int g = 0; g < 4; g += 2) {
+                        uint32_t o[2][2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float4 bv = bvq[ni][g + h];
+                            const int r0 = 4 * (g + h);
+                            o[h][0] = pack_bf16x2(act_apply(acc[mi][ni][r0 + 0] + bv.x, ACT), act_apply(acc[mi][ni][r0 + 1] + bv.y, ACT));
+                            o[h][1] = pack_bf16x2(act_apply(acc[mi][ni][r0 + 2] + bv.z, ACT), act_apply(acc[mi][ni][r0 + 3] + bv.w, ACT));
+                        }
+                        // vdst = group g, src = group g+1 (cdna guide T21)
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(o[0][0], o[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(o[0][1], o[1][1], false, false);
+                        uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        if (ok) {
+                            const int cofs = 32 * ni + 8 * g;
+                            if (ep) v = gate16<bf16_t>(v, *(const uint4*)(ep + cofs), a.egate_act);
+                            *(uint4*)(yp + cofs) = v;
+                        }
                     }
-                }
-        };
-        if (a.act == WU_ACT_RELU) epi_write(std::integral_constant<int, WU_ACT_RELU>{});
-        else if (a.act == WU_ACT_LEAKY) epi_write(std::integral_constant<int, WU_ACT_LEAKY>{});
-        else epi_write(std::integral_constant<int, WU_ACT_NONE>{});
-        WU_STAMP(t_epi_w);
-        __syncthreads();
-        WU_STAMP(t_epi_b2);
-        bf16_t* yout = a.y + (size_t)n * a.H * a.W * a.ldy + co0;
-#pragma unroll
-        for (int k = 0; k < K::P * 8 / 512; ++k) {
-            const int q = tid + 512 * k;
-            const int r = q >> 3, s = q & 7;
-            const int oh = oh0 + (r >> 5), ow = ow0 + (r & 31);
-            if (oh < a.H && ow < a.W) {
-                uint4 v = *(const uint4*)(epi + r * kRow + s * 16);
-                if (a.egate)
-                    v = gate16<bf16_t>(v, *(const uint4*)(a.egate + ((size_t)n * a.H * a.W + (size_t)(oh * a.W + ow)) * a.ldegate + co0 + s * 8), a.egate_act);
-                *(uint4*)(yout + (size_t)(oh * a.W + ow) * a.ldy + s * 8) = v;
             }
-        }
-        // the next chunk's top barrier orders these LDS reads before that buffer is DMA'd into again
-        stores_in_flight = (oh0 + K::TH <= a.H && ow0 + K::TW <= a.W) ? K::P * 8 / 512 : -1;
+        };
+        if (a.act == WU_ACT_RELU) epi_store(std::integral_constant<int, WU_ACT_RELU>{});
+        else if (a.act == WU_ACT_LEAKY) epi_store(std::integral_constant<int, WU_ACT_LEAKY>{});
+        else epi_store(std::integral_constant<int, WU_ACT_NONE>{});
+        // interior tile: every lane issued all NST stores (the counted vmcnt wait at the next chunk top relies on it)
+        stores_in_flight = oh0 + K::TH <= a.H && ow0 + K::TW <= a.W;
         WU_STAMP(t_epi_s);
     }
     if (a.dbg && lane == 0) {
         unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
-        d[0] = t_wait; d[1] = t_comp; d[2] = t_epi_b1; d[3] = t_epi_w; d[4] = t_epi_b2; d[5] = t_epi_s; d[6] = (unsigned long long)(t_end - t_begin); d[7] = nchunks;
+        d[0] = t_wait; d[1] = t_comp; d[2] = __builtin_readcyclecounter() - t_k0; d[3] = __builtin_amdgcn_s_memrealtime() - t_r0;   // in-kernel clock = d2 / d3 * 100 MHz
+         d[4] = t_epi_b2; d[5] = t_epi_s; d[6] = (unsigned long long)(t_end - t_begin); d[7] = nchunks;
     }
 #undef WU_STAMP
 }
@@ -306,9 +317,11 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     const long long grid = (ntiles < 256 || !g_wu_opt[WU_OPT_CONV_PERSISTENT]) ? ntiles : 256;
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_mfma_v2_kernel, dim3((int)grid), dim3(512), 2 * K::BUF, s, a);
+    if (g_wu_opt[WU_OPT_CONV_V2] == 2) hipLaunchKernelGGL(conv3x3_mfma_v2_kernel<4>, dim3((int)grid), dim3(256), 2 * K::BUF, s, a);
+    else hipLaunchKernelGGL(conv3x3_mfma_v2_kernel<8>, dim3((int)grid), dim3(512), 2 * K::BUF, s, a);
     return 0;
 }
