@@ -21,7 +21,7 @@ namespace {
 
 struct WgradArgs {
     const void* x; const void* dy; const void* y;
-    float* slab;       // [splits][9][Cout][Cin]
+    float* slab;       // [9][Cout][splits][Cin]: the partials of one output row are contiguous for the reducer
     float* bslab;      // [splits][Cout]
     int ldx, lddy, ldy;
     int N, H, W, Ho, Wo, Cin, Cout;
@@ -164,17 +164,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradArgs a
         __syncthreads();
     }
 
-    // ---- write the partial block: slab[split][tap][co][ci] ----
+    // ---- write the partial block: slab[tap][co][split][ci] ----
     {
         const int l31 = lane & 31, lh = lane >> 5;
-        float* sl = a.slab + (size_t)split * 9 * a.Cout * a.Cin;
+        float* sl = a.slab + (size_t)split * a.Cin;
+        const size_t rs = (size_t)a.splits * a.Cin;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int co = cob * 64 + 32 * wm + (i & 3) + 8 * (i >> 2) + 4 * lh;
                 const int ci = cib * 64 + 32 * wn + l31;
-                sl[((size_t)tap * a.Cout + co) * a.Cin + ci] = acc[tap][i];
+                sl[((size_t)tap * a.Cout + co) * rs + ci] = acc[tap][i];
             }
     }
     if (cib == 0 && a.bslab) {
@@ -185,32 +186,71 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradArgs a
     }
 }
 
-// sum the split-K slabs in fixed order (deterministic), transpose [tap][co][ci] -> OIHW, optional accumulate.
-// grid.y = tap; 4 independent partial sums keep 4 loads in flight per thread.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab, float* __restrict__ dw,
-                                    float* __restrict__ dbias, int splits, int Cout, int Cin, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int t = blockIdx.y;
-    const int total = Cout * Cin;
-    if (idx < total) {
-        const size_t stride = (size_t)9 * total;
-        const float* p = slab + (size_t)t * total + idx;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int k = 0;
-        for (; k + 4 <= splits; k += 4) {
-            s0 += p[(size_t)k * stride]; s1 += p[(size_t)(k + 1) * stride];
-            s2 += p[(size_t)(k + 2) * stride]; s3 += p[(size_t)(k + 3) * stride];
+// Fixed-order reduction of the split-K partials slab[tap][co][split][ci] (+ bias partials [split][Cout]) into OIHW fp32.
+// One block per (co, tap): its splits x Cin partials are ONE contiguous run, read as float4 by TX = Cin/4 lanes x G split
+// groups (group g takes splits g, g+G, ...; every load of an iteration is independent); the G partial sums are combined
+// in group order through LDS -> deterministic for a given (splits, Cin).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab, float* __restrict__ dw,
+                                                           float* __restrict__ dbias, int splits, int Cout, int Cin, int accumulate) {
+    __shared__ float4 red[256];
+    const int co = blockIdx.x, t = blockIdx.y;
+    const int c4n = Cin >> 2;
+    const int TX = c4n < 256 ? c4n : 256;
+    const int G = 256 / TX;
+    const int tx = threadIdx.x % TX, g = threadIdx.x / TX;
+    const float* row = slab + ((size_t)t * Cout + co) * splits * Cin;
+    for (int c4 = tx; c4 < c4n; c4 += TX) {          // one pass unless Cin > 1024
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < G) {
+            float4 a4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* p = row + c4 * 4;
+            int k = g;
+            for (; k + 3 * G < splits; k += 4 * G) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 v = *(const float4*)(p + (size_t)(k + u * G) * Cin);
+                    a4[u].x += v.x; a4[u].y += v.y; a4[u].z += v.z; a4[u].w += v.w;
+                }
+            }
+            for (; k < splits; k += G) {
+                const float4 v = *(const float4*)(p + (size_t)k * Cin);
+                a4[0].x += v.x; a4[0].y += v.y; a4[0].z += v.z; a4[0].w += v.w;
+            }
+            s.x = (a4[0].x + a4[1].x) + (a4[2].x + a4[3].x); s.y = (a4[0].y + a4[1].y) + (a4[2].y + a4[3].y);
+            s.z = (a4[0].z + a4[1].z) + (a4[2].z + a4[3].z); s.w = (a4[0].w + a4[1].w) + (a4[2].w + a4[3].w);
         }
-        for (; k < splits; ++k) s0 += p[(size_t)k * stride];
-        const float s = (s0 + s1) + (s2 + s3);
-        float* o = dw + (size_t)idx * 9 + t;
-        *o = accumulate ? *o + s : s;
+        if (G > 1) {
+            __syncthreads();
+            red[threadIdx.x] = s;
+            __syncthreads();
+            if (g == 0)
+                for (int j = 1; j < G; ++j) { const float4 v = red[j * TX + tx]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        }
+        if (g == 0) {
+            float* o = dw + ((size_t)co * Cin + c4 * 4) * 9 + t;
+            if (accumulate) { o[0] += s.x; o[9] += s.y; o[18] += s.z; o[27] += s.w; }
+            else { o[0] = s.x; o[9] = s.y; o[18] = s.z; o[27] = s.w; }
+        }
     }
-    if (dbias && t == 0 && idx < Cout) {
+    if (dbias && t == 0) {      // bias partials [split][Cout]: one load per thread, fixed-shape tree through LDS
         float b = 0.f;
-        for (int k = 0; k < splits; ++k) b += bslab[(size_t)k * Cout + idx];
-        dbias[idx] = accumulate ? dbias[idx] + b : b;
+        for (int k = threadIdx.x; k < splits; k += 256) b += bslab[(size_t)k * Cout + co];
+        float* rf = (float*)red;
+        __syncthreads();
+        rf[threadIdx.x] = b;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) rf[threadIdx.x] += rf[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) dbias[co] = accumulate ? dbias[co] + rf[0] : rf[0];
     }
+}
+
+void launch_wgrad_reduce(const float* slab, const float* bslab, float* dw, float* dbias, int splits, int Cout, int Cin, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout, 9), dim3(256), 0, s, slab, bslab, dw, dbias, splits, Cout, Cin, accumulate);
 }
 
 struct WPlan { int P, twl, tiles_x, tiles_y, ntiles, splits, halo_w, halo_h; size_t lds, ws; };
@@ -284,7 +324,7 @@ extern "C" int wu_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy
         wu_prof_pre(fam, s);
         wgrad_v2_launch(x, ldx, dy, lddy, slab, bslab, N, H, W, Cin, Cout, p2, s);
         wu_prof_post(fam, s, flops, bytes);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(Cout * Cin, 256), 9), dim3(256), 0, s, slab, bslab, dw_oihw, dbias, p2.splits, Cout, Cin, accumulate);
+        launch_wgrad_reduce(slab, bslab, dw_oihw, dbias, p2.splits, Cout, Cin, accumulate, s);
         WU_LAUNCH_CHECK("conv3x3_wgrad_v2");
         return 0;
     }
@@ -309,7 +349,7 @@ extern "C" int wu_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy
         if (stride == 1) launch_wgrad<float, 1, 128>(a, p.lds, grid, s); else launch_wgrad<float, 2, 64>(a, p.lds, grid, s);
     }
     wu_prof_post(fam, s, flops, bytes);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(Cout * Cin, 256), 9), dim3(256), 0, s, a.slab, a.bslab, dw_oihw, dbias, p.splits, Cout, Cin, accumulate);
+    launch_wgrad_reduce(a.slab, a.bslab, dw_oihw, dbias, p.splits, Cout, Cin, accumulate, s);
     WU_LAUNCH_CHECK("conv3x3_wgrad");
     return 0;
 }

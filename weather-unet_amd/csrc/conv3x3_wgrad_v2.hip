@@ -244,10 +244,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
         __syncthreads();
     }
 
-    // ---- partial block -> slab[split][tap][co][ci] ----
+    // ---- partial block -> slab[tap][co][split][ci] (the reducer reads one (tap, co) row's partials as a contiguous run) ----
     if (par == 0) {
         const int l31 = lane & 31, lh = lane >> 5;
-        float* sl = a.slab + (size_t)split * 9 * a.Cout * a.Cin;
+        float* sl = a.slab + (size_t)split * a.Cin;
+        const size_t rs = (size_t)a.splits * a.Cin;
         const int ci = cib * 64 + 32 * wci + l31;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int co = cob * 64 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * lh;
-                sl[((size_t)tap * a.Cout + co) * a.Cin + ci] = acc[t][i];
+                sl[((size_t)tap * a.Cout + co) * rs + ci] = acc[t][i];
             }
         }
     }
