@@ -318,7 +318,7 @@ extern "C" int wu_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy
     if (g_wu_opt[WU_OPT_WGRAD_V2] && wgrad_v2_eligible(H, W, Cin, Cout, stride, dtype, y != nullptr)) {
         const WgradV2Plan p2 = wgrad_v2_plan(N, H, W, Cin, Cout);
         WU_REQUIRE(workspace && workspace_bytes >= p2.ws && ((uintptr_t)workspace % 16) == 0, "conv3x3_wgrad: workspace too small (%zu < %zu)", workspace_bytes, p2.ws);
-        WU_REQUIRE((size_t)H * W * (size_t)(ldx > lddy ? ldx : lddy) * 2 < (1ull << 31), "conv3x3_wgrad: image too large for 32-bit offsets");
+        WU_REQUIRE(((size_t)H * W + W + 2) * (size_t)(ldx > lddy ? ldx : lddy) * 2 < (1ull << 31), "conv3x3_wgrad: image too large for 32-bit offsets");
         float* slab = (float*)workspace;
         float* bslab = dbias ? slab + (size_t)p2.splits * 9 * Cout * Cin : nullptr;
         wu_prof_pre(fam, s);

@@ -9,10 +9,11 @@
 //    2 dY fragments + 5 shifted X fragments feed 9 MFMAs (0.78 LDS fragment reads per MFMA instead of 1.1).
 //    The two wave sets take the even / odd K-steps of a tile and are summed through LDS at the end;
 //  * fragments come through ds_read_b64_tr_b16 (the reduction index, the pixel, is the slow NHWC index);
-//  * staging is LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass; the DMA of tile t+1 is in
-//    flight under the MFMAs of tile t (two LDS buffers, ONE barrier per tile).  Out-of-image halo pixels and
-//    ragged tile edges are DMA'd from a 16-byte zero constant (the per-lane SOURCE address is free); the LDS
-//    images are lane-linear, so the bank swizzle is applied to the source address (cdna guide rule 21);
+//  * staging is LDS-DMA (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass; the DMA of tile t+1 is in
+//    flight under the MFMAs of tile t (two LDS buffers, ONE barrier per tile).  One piece costs TWO instructions
+//    (s_mov m0 + buffer_load): the per-lane byte offsets are tile-invariant VGPRs, the tile origin travels in the
+//    scalar offset, and zero padding is the descriptor's range check (an out-of-range lane writes zeros to LDS);
+//    the LDS images are lane-linear, so the bank swizzle is applied to the source offset (cdna guide rule 21);
 //  * the tile is fixed at 8 x 32 pixels: every fragment address is lane_base + compile-time immediate, so the
 //    fully unrolled K loop contains no address arithmetic.
 #include <type_traits>
@@ -22,7 +23,6 @@
 
 namespace {
 
-__device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
 struct C {
     static constexpr int P = 256, TH = 8;                // pixels per tile (8 rows x 32)
@@ -30,30 +30,43 @@ struct C {
     static constexpr int HALO_W = 34, HALO_H = TH + 2, HALO_PIX = HALO_W * HALO_H;
     static constexpr int DY_BYTES = P * DY_ROW;          // 32 KiB
     static constexpr int DY_PIECES = DY_BYTES / 1024;    // 32 DMA pieces of 1 KiB
-    static constexpr int X_PIECES = (HALO_PIX * 128 + 1023) / 1024;   // 43
-    static constexpr int X_BYTES = X_PIECES * 1024;
-    static constexpr int BUF = DY_BYTES + X_BYTES;       // 76800 B; two buffers = 150 KiB
     static constexpr int NW = 8;                         // waves per workgroup
     static constexpr int NDY = DY_PIECES / NW;           // 4 DMA pieces per wave
-    static constexpr int NX = (X_PIECES + NW - 1) / NW;  // 6
+    static constexpr int NX = ((HALO_PIX * 128 + 1023) / 1024 + NW - 1) / NW;   // 6 (43 pieces carry halo pixels)
+    static constexpr int X_PIECES = NX * NW;             // 48: the 5 pad pieces are out of range for every lane (zeros)
+    static constexpr int X_BYTES = X_PIECES * 1024;
+    static constexpr int BUF = DY_BYTES + X_BYTES;       // 80 KiB; two buffers = all 160 KiB of the CU's LDS
 };
 
 struct W2Args {
     const bf16_t* x; const bf16_t* dy;
     float* slab; float* bslab;
+    unsigned long long* dbg;     // diagnostic: per-wave phase cycle sums (NULL in production)
     int ldx, lddy;
     int N, H, W, Cin, Cout;
     int tiles_x, tiles_y, ntiles, tiles_per_split, splits, co_blocks, ci_blocks;
     int dma_interleave;     // 1: spread the next tile's DMA issue over the first K-steps; 0: burst right after the barrier
 };
 
-// LDS-DMA from inline asm (see conv3x3_mfma_v2.hip): invisible to hipcc's waitcnt bookkeeping, so issuing it in the
-// middle of the MFMA loop does not make the compiler drain it before the next fragment read; the kernel waits for
-// it itself (dma_wait_all) ahead of the barrier that publishes the buffer.
-__device__ __forceinline__ void dma16(const void* g, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
+// LDS-DMA from inline asm: invisible to hipcc's waitcnt bookkeeping, so issuing it in the middle of the MFMA loop does
+// not make the compiler drain it before the next fragment read; the kernel waits for it itself (dma_wait_all) ahead of
+// the barrier that publishes the buffer.  M0 = wave-uniform LDS byte address of the 1-KiB piece (lane l lands at +16*l);
+// memory address = descriptor base + voff (per lane) + soff (scalar); voff + soff >= num_records -> that lane gets zeros.
+constexpr unsigned kOOB = 0x80000000u;
+typedef int rsrc_t __attribute__((ext_vector_type(4)));
+// raw buffer descriptor (stride 0, DATA_FORMAT 32: the gfx9 default word 3) from provably wave-uniform words (cdna guide T20)
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long u = (unsigned long long)(uintptr_t)base;
+    rsrc_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(u & 0xffffffffull));
+    r.y = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffull));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void dma16b(unsigned voff, rsrc_t rsrc, unsigned soff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_addr) : "memory", "m0");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint4 tr_frag(const char* p0) {
@@ -68,29 +81,40 @@ __device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& 
 // tap owned by accumulator slot i (0..3) of tap-half HF; slot 4 is the centre tap (4)
 template <int HF> __device__ __forceinline__ constexpr int tap_of(int i) { return i == 4 ? 4 : (HF ? 5 + i : i); }
 
+// One 256-pixel tile = 8 K-step pairs (kk) x 5 tap slots = 40 steps of 2 MFMAs (the centre-tap slot: 1).  Software-pipelined
+// by hand: the X fragment of step s+LA and the dY fragments of the NEXT kk are requested before the MFMAs of step s, so an
+// LDS round trip is always covered by matrix work (the compiler's own order was read-2 / wait / 2 MFMAs, latency exposed).
 template <int HF, typename Issue>
 __device__ __forceinline__ void compute_tile(const char* lds, const int (&a_lane)[2], const int (&b_lane)[3], f32x16_t (&acc)[9], Issue&& issue) {
+    auto load_a = [&](int kk, int m) __attribute__((always_inline)) { return tr_frag(lds + a_lane[m] + 32 * kk * C::DY_ROW); };
+    auto load_b = [&](int s_) __attribute__((always_inline)) {
+        const int kk = s_ / 5, i = s_ % 5;
+        const int tap = tap_of<HF>(i), kh = tap / 3, kw = tap % 3;
+        return tr_frag(lds + b_lane[kw] + kk * C::HALO_W * 128 + (kh * C::HALO_W + kw) * 128);
+    };
+    constexpr int LA = 2;                 // X-fragment look-ahead in steps (ring of LA + 1); 3 measured the same cycles
+    uint4 af[2][2], bf[LA + 1];
+    af[0][0] = load_a(0, 0);
+    af[0][1] = load_a(0, 1);
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
+    for (int j = 0; j < LA; ++j) bf[j] = load_b(j);
+#pragma unroll
+    for (int s_ = 0; s_ < 40; ++s_) {
+        const int kk = s_ / 5, i = s_ % 5;
         // the next tile's DMA pieces are issued inside the first K-steps: their address arithmetic overlaps MFMAs
-        issue(kk);
-        // K-step ks = 2*kk + parity covers tile pixels 32*kk + 16*parity + [0,16): tile row kk (parity is in the lane base)
-        const int a_off = 32 * kk * C::DY_ROW;
-        const int b_off = kk * C::HALO_W * 128;
-        uint4 af[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) af[m] = tr_frag(lds + a_lane[m] + a_off);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int tap = tap_of<HF>(i), kh = tap / 3, kw = tap % 3;
-            const uint4 bf = tr_frag(lds + b_lane[kw] + b_off + (kh * C::HALO_W + kw) * 128);
-            if (i < 4) {
-                mma(acc[2 * i], af[0], bf);
-                mma(acc[2 * i + 1], af[1], bf);
-            } else {
-                mma(acc[8], af[HF], bf);
-            }
+        if (i == 0) issue(kk);
+        if (s_ + LA < 40) bf[(s_ + LA) % (LA + 1)] = load_b(s_ + LA);
+        if (kk + 1 < 8 && i == 1) af[(kk + 1) & 1][0] = load_a(kk + 1, 0);
+        if (kk + 1 < 8 && i == 2) af[(kk + 1) & 1][1] = load_a(kk + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of this step's MFMAs
+        const uint4 b = bf[s_ % (LA + 1)];
+        if (i < 4) {
+            mma(acc[2 * i], af[kk & 1][0], b);
+            mma(acc[2 * i + 1], af[kk & 1][1], b);
+        } else {
+            mma(acc[8], af[kk & 1][HF], b);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -107,59 +131,58 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
     const int t_begin = split * a.tiles_per_split;
     const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
 
-    // ---- tile-invariant DMA descriptors, one packed register per 16-B item: LDS slot i = piece*64 + lane
-    //      -> (row << 8 | col | channel-slot << 16) of the pixel it is loaded from (-1: always zero) ----
-    int dy_d[C::NDY];
+    // ---- tile-invariant per-lane DMA byte offsets: LDS slot i = piece*64 + lane ----
+    // dY: slot -> (tile row r>>5, col r&31, swizzled channel slot) relative to the tile origin (always "valid": rows past
+    // the image fall off the end of the per-image descriptor)
+    unsigned dy_off[C::NDY];
 #pragma unroll
     for (int j = 0; j < C::NDY; ++j) {
         const int i = (C::NW * j + wave) * 64 + lane;
         const int r = i / C::DY_SLOTS, sl = i % C::DY_SLOTS;
         const int s = sl ^ (((r >> 1) & 1) << 2);
-        dy_d[j] = ((r >> 5) << 8) | (r & 31) | (s << 16);
+        dy_off[j] = (unsigned)((((r >> 5) * a.W + (r & 31)) * a.lddy + s * 8) * 2);
     }
-    int x_d[C::NX];
+    // X halo: slot -> halo pixel (hy, hx) relative to the halo origin (oh0-1, ow0-1); the descriptor base is shifted back
+    // by one row + one pixel so the offsets are non-negative.  x_flag marks the lanes that sit on a border the range check
+    // cannot see (top row / left / right column): they are pushed out of range on the tiles that touch that border.
+    unsigned x_off[C::NX], x_flag[C::NX];
 #pragma unroll
     for (int j = 0; j < C::NX; ++j) {
         const int i = (C::NW * j + wave) * 64 + lane;
         const int p = i >> 3, sl = i & 7;
         const int hy = p / C::HALO_W, hx = p - hy * C::HALO_W;
         const int s = sl ^ (((hx >> 1) & 1) << 2);
-        x_d[j] = (p < C::HALO_PIX && C::NW * j + wave < C::X_PIECES) ? ((hy << 8) | hx | (s << 16)) : -1;
+        x_off[j] = p < C::HALO_PIX ? (unsigned)(((hy * a.W + hx) * a.ldx + s * 8) * 2) : kOOB;
+        x_flag[j] = (hy == 0 ? 1u : 0u) | (hx == 0 ? 2u : 0u) | (hx == C::HALO_W - 1 ? 4u : 0u);
     }
 
-    // DMA of one tile = NDY + NX pieces per wave; `set_fetch_tile` decodes the tile once, `issue_piece(j)` issues piece j
+    // DMA of one tile = NDY + NX pieces per wave; `set_fetch_tile` decodes the tile once (scalar), `issue_piece(j)` issues piece j
     const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const char* dyb_f = nullptr;
-    const char* xb_f = nullptr;
-    int oh0_f = 0, ow0_f = 0;
+    const unsigned dy_img_bytes = (unsigned)((size_t)a.H * a.W * a.lddy * 2);
+    const unsigned x_img_bytes = (unsigned)((((size_t)a.H * a.W + a.W) * a.ldx + 64) * 2);
+    rsrc_t rs_dy = make_rsrc(a.dy, 0), rs_x = rs_dy;
+    unsigned so_dy = 0, so_x = 0, border_f = 0;
     auto set_fetch_tile = [&](int tile) __attribute__((always_inline)) {
         int tt = tile;
         const int tx = tt % a.tiles_x; tt /= a.tiles_x;
         const int ty = tt % a.tiles_y;
         const int n = tt / a.tiles_y;
-        oh0_f = ty * C::TH; ow0_f = tx * 32;
-        dyb_f = (const char*)(a.dy + ((size_t)n * a.H * a.W + (size_t)oh0_f * a.W + ow0_f) * a.lddy + cob * 64);
-        // x halo origin (oh0-1, ow0-1) may lie outside the image: keep it as a signed element offset
-        const long long xo = ((long long)n * a.H * a.W + (long long)(oh0_f - 1) * a.W + (ow0_f - 1)) * a.ldx + cib * 64;
-        xb_f = (const char*)a.x + xo * 2;
+        const int oh0 = ty * C::TH, ow0 = tx * 32;
+        rs_dy = make_rsrc(a.dy + (size_t)n * a.H * a.W * a.lddy + cob * 64, dy_img_bytes);
+        so_dy = (unsigned)__builtin_amdgcn_readfirstlane((oh0 * a.W + ow0) * a.lddy * 2);
+        // may point before the tensor for n = 0: never dereferenced (the lanes that would are flagged out of range)
+        rs_x = make_rsrc(a.x + ((long long)n * a.H * a.W - (a.W + 1)) * a.ldx + cib * 64, x_img_bytes);
+        so_x = (unsigned)__builtin_amdgcn_readfirstlane((oh0 * a.W + ow0) * a.ldx * 2);
+        border_f = (unsigned)__builtin_amdgcn_readfirstlane((int)((oh0 == 0 ? 1u : 0u) | (ow0 == 0 ? 2u : 0u) | (ow0 + 32 >= a.W ? 4u : 0u)));
     };
     auto issue_piece = [&](int j, int buf) __attribute__((always_inline)) {
         const unsigned lds = smem_base + buf * C::BUF;
         if (j < C::NDY) {
-            const int ty_ = (dy_d[j] >> 8) & 255, tx_ = dy_d[j] & 255, s_ = dy_d[j] >> 16;
-            const int rel = ((ty_ * a.W + tx_) * a.lddy + s_ * 8) * 2;
-            const void* g = (ty_ < a.H - oh0_f && tx_ < a.W - ow0_f) ? (const void*)(dyb_f + rel) : (const void*)&g_zero16;
-            dma16(g, __builtin_amdgcn_readfirstlane(lds + (C::NW * j + wave) * 1024));
+            dma16b(dy_off[j], rs_dy, so_dy, __builtin_amdgcn_readfirstlane(lds + (C::NW * j + wave) * 1024));
         } else {
             const int jj = j - C::NDY;
-            if (C::NW * jj + wave < C::X_PIECES) {             // wave-uniform
-                const int hy = (x_d[jj] >> 8) & 255, hx = x_d[jj] & 255, s_ = (x_d[jj] >> 16) & 15;
-                const int ih = oh0_f - 1 + hy, iw = ow0_f - 1 + hx;
-                const int rel = ((hy * a.W + hx) * a.ldx + s_ * 8) * 2;
-                const bool ok = x_d[jj] >= 0 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-                const void* g = ok ? (const void*)(xb_f + rel) : (const void*)&g_zero16;
-                dma16(g, __builtin_amdgcn_readfirstlane(lds + C::DY_BYTES + (C::NW * jj + wave) * 1024));
-            }
+            const unsigned vo = (x_flag[jj] & border_f) ? kOOB : x_off[jj];
+            dma16b(vo, rs_x, so_x, __builtin_amdgcn_readfirstlane(lds + C::DY_BYTES + (C::NW * jj + wave) * 1024));
         }
     };
 
@@ -188,6 +211,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
     const bool do_bias = (cib == 0) && (a.bslab != nullptr);
 
     // the tile loop is instantiated once per tap-half so each copy has a branch-free, fully unrolled body
+    unsigned long long t_wait = 0, t_bar = 0, t_comp = 0, t_mark = 0, t_k0 = 0, t_r0 = 0;
+#define WU_STAMP(v) do { if (a.dbg) { const unsigned long long t_ = __builtin_readcyclecounter(); v += t_ - t_mark; t_mark = t_; } } while (0)
+    if (a.dbg) { t_mark = t_k0 = __builtin_readcyclecounter(); t_r0 = __builtin_amdgcn_s_memrealtime(); }
     auto tile_loop = [&](auto hf_tag) __attribute__((always_inline)) {
         constexpr int HF = decltype(hf_tag)::value;
         if (t_begin < t_end) {
@@ -198,7 +224,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
         for (int tile = t_begin; tile < t_end; ++tile) {
             const int buf = (tile - t_begin) & 1;
             dma_wait_all();       // this wave's pieces of the tile have landed ...
+            WU_STAMP(t_wait);
             __syncthreads();      // ... and everyone else's; every wave is also done reading the other buffer
+            WU_STAMP(t_bar);
             const bool more = tile + 1 < t_end;
             if (more) set_fetch_tile(tile + 1);
             if (more && !a.dma_interleave) {
@@ -212,17 +240,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
                     bsum += bf16_to_f32(*(const bf16_t*)(lds + r * C::DY_ROW + ((co * 2) ^ (((r >> 1) & 1) << 6))));
             }
             compute_tile<HF>(lds, a_lane, b_lane, acc, [&](int kk) __attribute__((always_inline)) {
-                // 10 pieces over the first three K-steps (4 + 3 + 3)
-                if (more && a.dma_interleave && kk < 3) {
-                    const int j0 = kk == 0 ? 0 : (kk == 1 ? 4 : 7), j1 = kk == 0 ? 4 : (kk == 1 ? 7 : 10);
-#pragma unroll
-                    for (int j = j0; j < j1; ++j) issue_piece(j, buf ^ 1);
+                // 10 pieces, two per K-step pair over the first five
+                if (more && a.dma_interleave && kk < 5) {
+                    issue_piece(2 * kk, buf ^ 1);
+                    issue_piece(2 * kk + 1, buf ^ 1);
                 }
             });
+            WU_STAMP(t_comp);
         }
     };
     if (hf == 0) tile_loop(std::integral_constant<int, 0>{});
     else tile_loop(std::integral_constant<int, 1>{});
+    if (a.dbg && lane == 0) {
+        unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+        d[0] = t_wait; d[1] = t_comp; d[2] = __builtin_readcyclecounter() - t_k0; d[3] = __builtin_amdgcn_s_memrealtime() - t_r0;
+        d[4] = t_bar; d[5] = 0; d[6] = (unsigned long long)(t_end - t_begin); d[7] = 0;
+    }
+#undef WU_STAMP
     __syncthreads();   // all fragment reads done: LDS is free for the reductions below
 
     // ---- add the odd-K-step wave set into the even one through LDS ----
@@ -277,7 +311,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
 }  // namespace
 
 bool wgrad_v2_eligible(int H, int W, int Cin, int Cout, int stride, int dtype, bool gated) {
-    return dtype == WU_BF16 && stride == 1 && !gated && W > 16 && Cin % 64 == 0 && Cout % 64 == 0;
+    // W % 32: whole tile columns (left / right zero padding is per-tile flags, a ragged right edge is not handled here)
+    return dtype == WU_BF16 && stride == 1 && !gated && W % 32 == 0 && Cin % 64 == 0 && Cout % 64 == 0;
 }
 
 WgradV2Plan wgrad_v2_plan(int N, int H, int W, int Cin, int Cout) {
@@ -304,6 +339,7 @@ int wgrad_v2_launch(const void* x, int ldx, const void* dy, int lddy, float* sla
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
     a.splits = p.splits; a.co_blocks = p.co_blocks; a.ci_blocks = p.ci_blocks;
     a.dma_interleave = g_wu_opt[WU_OPT_WGRAD_DMA_INTERLEAVE];
+    a.dbg = (unsigned long long*)g_wu_dbg_ptr;
     const int grid = p.splits * p.co_blocks * p.ci_blocks;
     static thread_local bool attr_set = false;
     if (!attr_set) {
