@@ -4,10 +4,11 @@
 // Same algorithm as conv3x3_mfma.hip (per 64-byte channel chunk: halo tile + [9][64][chunk] weight slab in LDS,
 // tap shift = LDS address offset, no im2col), re-built the way the weight-gradient kernel was:
 //   * 8 waves (2 per SIMD) share one 16x32-pixel x 64-Cout tile: the weight slab is staged once per 512 pixels;
-//   * staging is LDS-DMA (global_load_lds_dwordx4) into TWO buffers: chunk k+1 streams in under the MFMAs of
-//     chunk k, one barrier per chunk, no staging registers, no ds_write pass.  Out-of-image halo pixels come
-//     from a 16-byte zero constant; the XOR bank swizzle is applied to the per-lane SOURCE address (the LDS image
-//     of a DMA is lane-linear);
+//   * staging is LDS-DMA (buffer_load_dwordx4 ... lds) into TWO buffers: chunk k+1 streams in under the MFMAs of
+//     chunk k, one barrier per chunk, no staging registers, no ds_write pass.  A piece costs two instructions: the
+//     per-lane byte offsets are tile-invariant registers, tile origin and chunk travel in the scalar offset, and
+//     out-of-image halo pixels are lanes pushed out of the descriptor's range (they write zeros); the XOR bank
+//     swizzle is applied to the per-lane SOURCE offset (the LDS image of a DMA is lane-linear);
 //   * the DMA issue of the next chunk is spread over the nine taps of the current one (its address VALU work
 //     hides behind the MFMAs instead of sitting between the barrier and the first fragment read);
 //   * tile width fixed at 32: fragment addresses are lane_base[kw][ks] + immediate, no VALU in the tap loop.
@@ -18,23 +19,22 @@
 
 namespace {
 
-__device__ const uint4 g_zero16v2 = {0u, 0u, 0u, 0u};
-
 struct K {
     static constexpr int TH = 16, TW = 32, P = TH * TW;          // 512 output pixels
     static constexpr int HALO_W = TW + 2, HALO_H = TH + 2, HALO_PIX = HALO_W * HALO_H;   // 34 x 18 = 612
-    static constexpr int H_PIECES = (HALO_PIX * 64 + 1023) / 1024;   // 39
-    static constexpr int H_BYTES = H_PIECES * 1024;
-    static constexpr int W_PIECES = 9 * 64 * 64 / 1024;              // 36
-    static constexpr int W_BYTES = W_PIECES * 1024;
-    static constexpr int BUF = H_BYTES + W_BYTES;                    // 76800 B, two buffers = 150 KiB
+    // 1-KiB DMA pieces: 39 carry halo pixels, 36 carry weights; both regions are padded to 40 so every wave issues the same
+    // number of pieces with no guard (the pad pieces are out of range for every lane: zeros into unused LDS)
+    static constexpr int H_PIECES = 40, H_BYTES = H_PIECES * 1024;
+    static constexpr int W_REAL = 9 * 64 * 64 / 1024;                // 36
+    static constexpr int W_PIECES = 40, W_BYTES = W_PIECES * 1024;
+    static constexpr int BUF = H_BYTES + W_BYTES;                    // 80 KiB, two buffers = all 160 KiB of the CU's LDS
 };
 // NW waves share the tile: 8 (two per SIMD, 2 tile rows = 4 accumulators each) or 4 (one per SIMD, 4 rows = 8 accumulators)
 template <int NW_> struct KW {
     static constexpr int NW = NW_;
     static constexpr int RPW = K::TH / NW;                               // tile rows per wave
-    static constexpr int NH = (K::H_PIECES + NW - 1) / NW;               // halo pieces per wave
-    static constexpr int NWT = (K::W_PIECES + NW - 1) / NW;              // weight pieces per wave
+    static constexpr int NH = K::H_PIECES / NW;                          // halo pieces per wave
+    static constexpr int NWT = K::W_PIECES / NW;                         // weight pieces per wave
     static constexpr int NP = NH + NWT;
     static constexpr int NST = K::P * 8 / (NW * 64);                     // 16-B output stores per thread and tile
 };
@@ -47,14 +47,6 @@ struct V2Args {
     unsigned long long* dbg;     // diagnostic: per-workgroup phase cycle sums (NULL in production)
 };
 
-// LDS-DMA issued from inline asm: hipcc cannot see it, so it neither drains it (vmcnt(0)) before the next
-// ds_read of the OTHER buffer nor counts it -- the kernel waits for it itself (dma_wait_all) before the barrier
-// that publishes the buffer (cdna guide 5.7: M0 = wave-uniform LDS byte address, restored in the same statement).
-__device__ __forceinline__ void dma16(const void* g, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
-}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
@@ -74,30 +66,36 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
     const int t_end = (int)((long long)a.ntiles * (wg + 1) / gridDim.x);
     if (t_begin >= t_end) return;
 
-    // ---- tile-invariant parts of the DMA descriptors: LDS slot i = piece*64 + lane ----
-    // halo: pixel p = i >> 2, LDS 16-B slot sl = i & 3 holds channel slot sl ^ swz(hx); packed (hy << 8 | hx | s << 16), -1 = never valid
-    int hdesc[Q::NH];
+    // ---- tile-invariant per-lane DMA byte offsets (wu_common.h, wu_dma16b): LDS slot i = piece*64 + lane ----
+    // halo: pixel p = i >> 2 = (hy, hx) relative to the halo origin (oh0-1, ow0-1), LDS 16-B slot sl = i & 3 holds channel
+    // slot sl ^ swz(hx).  The descriptor base is shifted back by one row + one pixel so the offsets are non-negative.
+    unsigned hoff[Q::NH];
+    int hpos[Q::NH];
 #pragma unroll
     for (int j = 0; j < Q::NH; ++j) {
         const int i = (NW * j + wave) * 64 + lane;
         const int p = i >> 2, sl = i & 3;
         const int hy = p / K::HALO_W, hx = p - hy * K::HALO_W;
-        hdesc[j] = (p < K::HALO_PIX) ? ((hy << 8) | hx | ((sl ^ ((hx >> 2) & 3)) << 16)) : -1;
+        hoff[j] = p < K::HALO_PIX ? (unsigned)(((hy * a.W + hx) * a.ldx + (sl ^ ((hx >> 2) & 3)) * 8) * 2) : kWuOOB;
+        hpos[j] = (hy << 8) | hx;
     }
-    // weights: row = i >> 2 = tap*64 + co, slot sl holds channel slot sl ^ swz(co): element offset relative to cout tile 0
-    int wrel[Q::NWT];
+    // weights: row = i >> 2 = tap*64 + co, slot sl holds channel slot sl ^ swz(co): byte offset relative to the cout tile
+    unsigned woff[Q::NWT];
 #pragma unroll
     for (int j = 0; j < Q::NWT; ++j) {
         const int i = (NW * j + wave) * 64 + lane;
         const int row = i >> 2, sl = i & 3;
         const int tap = row >> 6, co = row & 63;
-        wrel[j] = (tap * a.Cout + co) * a.Cin + (sl ^ ((co >> 2) & 3)) * 8;     // < 9*512*768 elements: fits int32
+        woff[j] = NW * j + wave < K::W_REAL ? (unsigned)(((tap * a.Cout + co) * a.Cin + (sl ^ ((co >> 2) & 3)) * 8) * 2) : kWuOOB;
     }
 
-    // descriptors of the tile whose chunks are currently being FETCHED (one tile ahead at tile boundaries)
-    int hsrc[Q::NH];
-    const bf16_t* xin_f = nullptr;
-    const bf16_t* w_f = nullptr;
+    // descriptors of the tile whose chunks are currently being FETCHED (one tile ahead at tile boundaries): scalar state
+    // (two buffer descriptors, the tile's byte offset) + the halo offsets with this tile's border lanes pushed out of range
+    // (top row / left / right columns; rows past the bottom fall off the end of the per-image descriptor by themselves)
+    const unsigned x_img_bytes = (unsigned)((((size_t)a.H * a.W + a.W) * a.ldx + a.Cin) * 2);
+    unsigned hv[Q::NH];
+    wu_rsrc_t rs_x = wu_make_rsrc(a.x, 0), rs_w = rs_x;
+    unsigned so_tile = 0;
     auto set_fetch_tile = [&](int tile) __attribute__((always_inline)) {
         int tt = tile, ct;
         if (a.ct_slowest) { const int per = a.ntiles / a.cout_tiles; ct = tt / per; tt -= ct * per; }
@@ -106,29 +104,28 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         const int ty = tt % a.tiles_y;
         const int n = tt / a.tiles_y;
         const int oh0 = ty * K::TH, ow0 = tx * K::TW;
-        xin_f = a.x + (size_t)n * a.H * a.W * a.ldx;
-        w_f = a.w + (size_t)ct * 64 * a.Cin;
+        // may point before the tensor for n = 0: never dereferenced (the lanes that would are out of range below)
+        rs_x = wu_make_rsrc(a.x + ((long long)n * a.H * a.W - (a.W + 1)) * a.ldx, x_img_bytes);
+        rs_w = wu_make_rsrc(a.w + (size_t)ct * 64 * a.Cin, (unsigned)(((size_t)9 * a.Cout - (size_t)ct * 64) * a.Cin * 2));
+        so_tile = (unsigned)__builtin_amdgcn_readfirstlane((oh0 * a.W + ow0) * a.ldx * 2);
+        const int ymin = __builtin_amdgcn_readfirstlane(oh0 == 0 ? 1 : 0), xmin = __builtin_amdgcn_readfirstlane(ow0 == 0 ? 1 : 0);
+        const int xmax = __builtin_amdgcn_readfirstlane(a.W - ow0);
 #pragma unroll
         for (int j = 0; j < Q::NH; ++j) {
-            const int hy = (hdesc[j] >> 8) & 255, hx = hdesc[j] & 255, s_ = (hdesc[j] >> 16) & 3;
-            const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
-            hsrc[j] = (hdesc[j] >= 0 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) ? (ih * a.W + iw) * a.ldx + s_ * 8 : -1;
+            const int hy = hpos[j] >> 8, hx = hpos[j] & 255;
+            hv[j] = (hy >= ymin && hx >= xmin && hx <= xmax) ? hoff[j] : kWuOOB;
         }
     };
 
     const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    // one piece = s_mov m0 + buffer_load ... lds; c0 (the chunk's first channel) travels in the scalar offset
     auto issue_piece = [&](int j, int c0, int buf) __attribute__((always_inline)) {
         const unsigned lds = smem_base + buf * K::BUF;
-        // j in [0, NH): halo piece; j in [NH, NH + NWT): weight piece (wave-uniform guards)
         if (j < Q::NH) {
-            if (NW * j + wave < K::H_PIECES) {
-                const void* g = hsrc[j] >= 0 ? (const void*)(xin_f + hsrc[j] + c0) : (const void*)&g_zero16v2;
-                dma16(g, __builtin_amdgcn_readfirstlane(lds + (NW * j + wave) * 1024));
-            }
+            wu_dma16b(hv[j], rs_x, so_tile + (unsigned)c0 * 2, __builtin_amdgcn_readfirstlane(lds + (NW * j + wave) * 1024));
         } else {
             const int jj = j - Q::NH;
-            if (NW * jj + wave < K::W_PIECES)
-                dma16((const void*)(w_f + wrel[jj] + c0), __builtin_amdgcn_readfirstlane(lds + K::H_BYTES + (NW * jj + wave) * 1024));
+            wu_dma16b(woff[jj], rs_w, (unsigned)c0 * 2, __builtin_amdgcn_readfirstlane(lds + K::H_BYTES + (NW * jj + wave) * 1024));
         }
     };
 
@@ -296,9 +293,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
 
 }  // namespace
 
-bool conv_v2_eligible(int H, int W, int Cin, int Cout, int stride, int dtype, bool masked) {
-    return dtype == WU_BF16 && stride == 1 && !masked && W > 16 && Cin % 32 == 0 && Cout % 64 == 0 &&
-           (size_t)9 * Cout * Cin < (1ull << 31);
+bool conv_v2_eligible(int H, int W, int ldx, int Cin, int Cout, int stride, int dtype, bool masked) {
+    // 32-bit DMA byte offsets below kWuOOB: the weight pack and one (row + pixel padded) image
+    return dtype == WU_BF16 && stride == 1 && !masked && W > 16 && W <= 4096 && Cin % 32 == 0 && Cout % 64 == 0 &&
+           (size_t)9 * Cout * Cin * 2 < (1ull << 31) && ((size_t)H * W + W + 2) * (size_t)ldx * 2 < (1ull << 31);
 }
 
 int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,

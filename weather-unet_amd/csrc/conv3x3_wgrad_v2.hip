@@ -48,26 +48,6 @@ struct W2Args {
     int dma_interleave;     // 1: spread the next tile's DMA issue over the first K-steps; 0: burst right after the barrier
 };
 
-// LDS-DMA from inline asm: invisible to hipcc's waitcnt bookkeeping, so issuing it in the middle of the MFMA loop does
-// not make the compiler drain it before the next fragment read; the kernel waits for it itself (dma_wait_all) ahead of
-// the barrier that publishes the buffer.  M0 = wave-uniform LDS byte address of the 1-KiB piece (lane l lands at +16*l);
-// memory address = descriptor base + voff (per lane) + soff (scalar); voff + soff >= num_records -> that lane gets zeros.
-constexpr unsigned kOOB = 0x80000000u;
-typedef int rsrc_t __attribute__((ext_vector_type(4)));
-// raw buffer descriptor (stride 0, DATA_FORMAT 32: the gfx9 default word 3) from provably wave-uniform words (cdna guide T20)
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
-    const unsigned long long u = (unsigned long long)(uintptr_t)base;
-    rsrc_t r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(u & 0xffffffffull));
-    r.y = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffull));
-    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-    r.w = 0x00020000;
-    return r;
-}
-__device__ __forceinline__ void dma16b(unsigned voff, rsrc_t rsrc, unsigned soff, unsigned lds_byte_addr) {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_addr) : "memory", "m0");
-}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint4 tr_frag(const char* p0) {
     const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)p0);
@@ -152,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
         const int p = i >> 3, sl = i & 7;
         const int hy = p / C::HALO_W, hx = p - hy * C::HALO_W;
         const int s = sl ^ (((hx >> 1) & 1) << 2);
-        x_off[j] = p < C::HALO_PIX ? (unsigned)(((hy * a.W + hx) * a.ldx + s * 8) * 2) : kOOB;
+        x_off[j] = p < C::HALO_PIX ? (unsigned)(((hy * a.W + hx) * a.ldx + s * 8) * 2) : kWuOOB;
         x_flag[j] = (hy == 0 ? 1u : 0u) | (hx == 0 ? 2u : 0u) | (hx == C::HALO_W - 1 ? 4u : 0u);
     }
 
@@ -160,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
     const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned dy_img_bytes = (unsigned)((size_t)a.H * a.W * a.lddy * 2);
     const unsigned x_img_bytes = (unsigned)((((size_t)a.H * a.W + a.W) * a.ldx + 64) * 2);
-    rsrc_t rs_dy = make_rsrc(a.dy, 0), rs_x = rs_dy;
+    wu_rsrc_t rs_dy = wu_make_rsrc(a.dy, 0), rs_x = rs_dy;
     unsigned so_dy = 0, so_x = 0, border_f = 0;
     auto set_fetch_tile = [&](int tile) __attribute__((always_inline)) {
         int tt = tile;
@@ -168,21 +148,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
         const int ty = tt % a.tiles_y;
         const int n = tt / a.tiles_y;
         const int oh0 = ty * C::TH, ow0 = tx * 32;
-        rs_dy = make_rsrc(a.dy + (size_t)n * a.H * a.W * a.lddy + cob * 64, dy_img_bytes);
+        rs_dy = wu_make_rsrc(a.dy + (size_t)n * a.H * a.W * a.lddy + cob * 64, dy_img_bytes);
         so_dy = (unsigned)__builtin_amdgcn_readfirstlane((oh0 * a.W + ow0) * a.lddy * 2);
         // may point before the tensor for n = 0: never dereferenced (the lanes that would are flagged out of range)
-        rs_x = make_rsrc(a.x + ((long long)n * a.H * a.W - (a.W + 1)) * a.ldx + cib * 64, x_img_bytes);
+        rs_x = wu_make_rsrc(a.x + ((long long)n * a.H * a.W - (a.W + 1)) * a.ldx + cib * 64, x_img_bytes);
         so_x = (unsigned)__builtin_amdgcn_readfirstlane((oh0 * a.W + ow0) * a.ldx * 2);
         border_f = (unsigned)__builtin_amdgcn_readfirstlane((int)((oh0 == 0 ? 1u : 0u) | (ow0 == 0 ? 2u : 0u) | (ow0 + 32 >= a.W ? 4u : 0u)));
     };
     auto issue_piece = [&](int j, int buf) __attribute__((always_inline)) {
         const unsigned lds = smem_base + buf * C::BUF;
         if (j < C::NDY) {
-            dma16b(dy_off[j], rs_dy, so_dy, __builtin_amdgcn_readfirstlane(lds + (C::NW * j + wave) * 1024));
+            wu_dma16b(dy_off[j], rs_dy, so_dy, __builtin_amdgcn_readfirstlane(lds + (C::NW * j + wave) * 1024));
         } else {
             const int jj = j - C::NDY;
-            const unsigned vo = (x_flag[jj] & border_f) ? kOOB : x_off[jj];
-            dma16b(vo, rs_x, so_x, __builtin_amdgcn_readfirstlane(lds + C::DY_BYTES + (C::NW * jj + wave) * 1024));
+            const unsigned vo = (x_flag[jj] & border_f) ? kWuOOB : x_off[jj];
+            wu_dma16b(vo, rs_x, so_x, __builtin_amdgcn_readfirstlane(lds + C::DY_BYTES + (C::NW * jj + wave) * 1024));
         }
     };
 

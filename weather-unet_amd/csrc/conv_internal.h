@@ -2,6 +2,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-bool conv_v2_eligible(int H, int W, int Cin, int Cout, int stride, int dtype, bool masked);
+bool conv_v2_eligible(int H, int W, int ldx, int Cin, int Cout, int stride, int dtype, bool masked);
 int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
                    const void* egate, int ldegate, int egate_act, int N, int H, int W, int Cin, int Cout, int act, hipStream_t s);

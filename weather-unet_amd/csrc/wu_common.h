@@ -114,6 +114,29 @@ template <typename T> __device__ __forceinline__ uint4 gate16(const uint4& g, co
     return pack16<T>(gf);
 }
 
+// ---- LDS-DMA through a buffer descriptor (buffer_load_dwordx4 ... lds) -----------------------------------------------
+// Issued from inline asm: invisible to hipcc's waitcnt bookkeeping, so issuing it inside an MFMA loop does not make the
+// compiler drain it before the next ds_read; the kernel waits for it itself (s_waitcnt vmcnt) ahead of the barrier that
+// publishes the buffer.  M0 = wave-uniform LDS byte address of the 1-KiB piece (lane l lands at +16*l); memory address =
+// descriptor base + voff (per lane) + soff (scalar); a lane with voff + soff >= num_records writes ZEROS to LDS (probed on
+// gfx950: scratch/micro/buflds.hip) -- zero padding costs no select and no branch.
+typedef int wu_rsrc_t __attribute__((ext_vector_type(4)));
+constexpr unsigned kWuOOB = 0x80000000u;
+// raw buffer descriptor (stride 0, word 3 = DATA_FORMAT 32) from provably wave-uniform words (cdna guide T20)
+__device__ __forceinline__ wu_rsrc_t wu_make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long u = (unsigned long long)(uintptr_t)base;
+    wu_rsrc_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(u & 0xffffffffull));
+    r.y = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffull));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void wu_dma16b(unsigned voff, wu_rsrc_t rsrc, unsigned soff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_addr) : "memory", "m0");
+}
+
 // ---- XCD-aware block remap ------------------------------------------------------------------------
 // Blocks are dealt round-robin over the 8 XCDs (private 4 MiB L2 each).  Remap so each XCD owns a
 // contiguous range of logical tile ids: neighbouring tiles (shared halos / same input tile for
