@@ -7,7 +7,7 @@ from wu.layout import empty_nhwc
 dev = torch.device('cuda:0')
 B = 32
 layers = [('d1.2', 64, 64, 256), ('d2.2', 128, 128, 128), ('d3.2', 256, 256, 64), ('d4.2', 512, 512, 32), ('u3.0', 768, 256, 64), ('u2.0', 384, 128, 128), ('u1.0', 192, 64, 256), ('dg u1.0', 64, 192, 256)]
-variants = {'v1': (0, 0), 'v2 8 waves': (1, 1), 'v2 4 waves': (2, 1)}
+variants = {'v1': (0, 0), 'v2 8 waves': (3, 1), 'v2 4 waves': (2, 1)}
 def run(fn, reps=3):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()

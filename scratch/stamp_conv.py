@@ -4,6 +4,8 @@ import torch
 from wu import _lib, kernels as K
 from wu.layout import empty_nhwc
 dev = torch.device('cuda:0'); B = 32
+NWAVES = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+_lib.call('wu_set_option', 0, 3 if NWAVES == 8 else 2)
 dbg = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
 for name, ci, co, s in [('d1.2', 64, 64, 256), ('d2.2', 128, 128, 128), ('d4.2', 512, 512, 32), ('u1.0', 192, 64, 256)]:
     x = (torch.rand((B, s, s, ci), device=dev) * 2 - 1).to(torch.bfloat16).permute(0, 3, 1, 2)
@@ -16,7 +18,7 @@ for name, ci, co, s in [('d1.2', 64, 64, 256), ('d2.2', 128, 128, 128), ('d4.2',
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); K.conv3x3(x, wf, bias, y, 1, 1); e1.record(); torch.cuda.synchronize()
     _lib.call('wu_set_debug_buffer', None)
-    d = dbg.view(256, 8, 8).double().cpu()
+    d = dbg.view(256, 8, 8).double().cpu()[:, :NWAVES]
     tiles, chunks = d[0, 0, 6].item(), d[0, 0, 7].item()
     clk = (d[:, 0, 2] / d[:, 0, 3]).median().item() * 0.1
     ph = d[:, :, :6].mean(dim=(0, 1)); ph[2] = 0; ph[3] = 0

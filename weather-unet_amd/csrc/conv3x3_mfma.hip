@@ -326,7 +326,7 @@ extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, cons
     hipStream_t s = (hipStream_t)stream;
     const bool m = mask != nullptr;
     const int fam = stride == 2 ? WU_FAM_CONV_S2 : (m ? WU_FAM_CONV_DGRAD : WU_FAM_CONV_FWD);
-    if (g_wu_opt[WU_OPT_CONV_V2] && conv_v2_eligible(H, W, ldx, Cin, Cout, stride, dtype, m)) {
+    if (g_wu_opt[WU_OPT_CONV_V2] && conv_v2_eligible(H, W, ldx, Cin, Cout, stride, dtype, m) && (egate == nullptr || act == WU_ACT_NONE)) {
         wu_prof_pre(fam, s);
         const int rc = conv_v2_launch(x, ldx, w_packed, bias, y, ldy, egate, ldegate, egate_act, N, H, W, Cin, Cout, act, s);
         WU_REQUIRE(rc == 0, "conv3x3_fwd: grid too large");

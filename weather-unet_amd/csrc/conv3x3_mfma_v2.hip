@@ -47,6 +47,21 @@ struct V2Args {
     unsigned long long* dbg;     // diagnostic: per-workgroup phase cycle sums (NULL in production)
 };
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+// ReLU of a packed bf16 pair: as int16 a negative float is negative, a positive one positive -> v_pk_max_i16 with 0
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t d) {
+    const s16x2_t v = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, d), s16x2_t{0, 0});
+    return __builtin_bit_cast(uint32_t, v);
+}
+// g * ReLU'(y) on packed bf16 pairs: keep a half iff y != 0 and y's sign bit is clear (y > 0)
+__device__ __forceinline__ uint32_t relu_gate_bf16x2(uint32_t g, uint32_t y) {
+    const u16x2_t nz = __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, y), u16x2_t{1, 1});
+    const u16x2_t m = u16x2_t{0, 0} - nz;                                              // 0xffff where y != 0
+    const s16x2_t sg = __builtin_bit_cast(s16x2_t, y) >> s16x2_t{15, 15};               // 0xffff where y < 0
+    return g & __builtin_bit_cast(uint32_t, m) & ~__builtin_bit_cast(uint32_t, sg);
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
@@ -119,13 +134,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
 
     const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     // one piece = s_mov m0 + buffer_load ... lds; c0 (the chunk's first channel) travels in the scalar offset
-    auto issue_piece = [&](int j, int c0, int buf) __attribute__((always_inline)) {
+    // (kill = kWuOOB turns the piece into an all-lanes-out-of-range no-op that still lands zeros: branch-free "no more chunks")
+    auto issue_piece = [&](int j, int c0, int buf, unsigned kill = 0u) __attribute__((always_inline)) {
         const unsigned lds = smem_base + buf * K::BUF;
         if (j < Q::NH) {
-            wu_dma16b(hv[j], rs_x, so_tile + (unsigned)c0 * 2, __builtin_amdgcn_readfirstlane(lds + (NW * j + wave) * 1024));
+            wu_dma16b(hv[j], rs_x, (so_tile + (unsigned)c0 * 2) | kill, __builtin_amdgcn_readfirstlane(lds + (NW * j + wave) * 1024));
         } else {
             const int jj = j - Q::NH;
-            wu_dma16b(woff[jj], rs_w, (unsigned)c0 * 2, __builtin_amdgcn_readfirstlane(lds + K::H_BYTES + (NW * jj + wave) * 1024));
+            wu_dma16b(woff[jj], rs_w, ((unsigned)c0 * 2) | kill, __builtin_amdgcn_readfirstlane(lds + K::H_BYTES + (NW * jj + wave) * 1024));
         }
     };
 
@@ -170,6 +186,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         // Requested right AFTER chunk 0's wait (below), not here: a load issued between the previous epilogue's stores and
         // that wait would be the youngest vector-memory op and make the counted vmcnt wait drain the stores.
         float4 bvq[2][4];
+        uint4 egv[Q::RPW][2][2];      // gate values (dgrad): prefetched in the last chunk
         for (int c = 0; c < nchunks; ++c) {
             const char* lds = smem + buf * K::BUF;
             const int nxt = buf ^ 1;
@@ -195,6 +212,25 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                         bvq[ni][g] = a.bias ? *(const float4*)(a.bias + ct_ * 64 + 32 * ni + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             if (last && more) set_fetch_tile(tile + 1);
+            // the gate values of this tile's outputs are requested at the start of its LAST chunk: they land under the MFMAs
+            // instead of stalling every store of the epilogue (out-of-image pixels are clamped, their stores are skipped)
+            if (last && a.egate) {
+                int tt_ = tile, ct_;
+                if (a.ct_slowest) { const int per = a.ntiles / a.cout_tiles; ct_ = tt_ / per; tt_ -= ct_ * per; }
+                else { ct_ = tt_ % a.cout_tiles; tt_ /= a.cout_tiles; }
+                const int tx_ = tt_ % a.tiles_x; tt_ /= a.tiles_x;
+                const int ty_ = tt_ % a.tiles_y;
+                const int n_ = tt_ / a.tiles_y;
+#pragma unroll
+                for (int mi = 0; mi < Q::RPW; ++mi) {
+                    const int oh = min(ty_ * K::TH + Q::RPW * wave + mi, a.H - 1), ow = min(tx_ * K::TW + l31, a.W - 1);
+                    const bf16_t* ep = a.egate + ((size_t)n_ * a.H * a.W + (size_t)(oh * a.W + ow)) * a.ldegate + ct_ * 64 + 8 * lh;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) egv[mi][ni][gp] = *(const uint4*)(ep + 32 * ni + 16 * gp);
+                }
+            }
             // 18 steps (tap, ks), software-pipelined by hand: the fragments of step s+1 are requested BEFORE the four
             // MFMAs of step s are issued, so one LDS round trip is always covered by matrix work of this wave
             // (a 2-step look-ahead measured 2-3 % slower).
@@ -208,21 +244,55 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                     bf[ni] = *(const uint4*)(lds + b_lane[ks] + (tap * 64 + 32 * ni) * 64);
             };
             uint4 af[2][Q::RPW], bf[2][2];
-            load_step(0, af[0], bf[0]);
+            if constexpr (NW == 8) {
+                load_step(0, af[0], bf[0]);
 #pragma unroll
-            for (int step = 0; step < 18; ++step) {
-                const int cur = step & 1;
-                if (step + 1 < 18) load_step(step + 1, af[cur ^ 1], bf[cur ^ 1]);
-                // issue the next chunk's DMA pieces (10 per wave at NW=8, 19 at NW=4) at the START of this chunk (2 per step): their address
-                // VALU work hides behind MFMAs and they get ~3/4 of the chunk to land (LDS-DMA latency ~1.2 us)
-                if (more && 2 * step < Q::NP) {
-                    issue_piece(2 * step, c1, nxt);
-                    if (2 * step + 1 < Q::NP) issue_piece(2 * step + 1, c1, nxt);
+                for (int step = 0; step < 18; ++step) {
+                    const int cur = step & 1;
+                    if (step + 1 < 18) load_step(step + 1, af[cur ^ 1], bf[cur ^ 1]);
+                    // issue the next chunk's 10 DMA pieces at the START of this chunk (2 per step): they get ~3/4 of the chunk to
+                    // land (LDS-DMA latency ~1.2 us)
+                    if (more && 2 * step < Q::NP) {
+                        issue_piece(2 * step, c1, nxt);
+                        if (2 * step + 1 < Q::NP) issue_piece(2 * step + 1, c1, nxt);
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < Q::RPW; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) mma(acc[mi][ni], bf[cur][ni], af[cur][mi]);   // D^T = W * X^T
                 }
+            } else {
+                // ONE wave per SIMD: nothing else fills the matrix pipe while this wave issues loads, so the stream is pinned
+                // instruction by instruction: after MFMA m of step s comes fragment read m of step s+1 (6 reads over the
+                // first 6 of 8 MFMAs), the DMA pieces ride behind the last MFMA; the whole chunk is one basic block.
+                constexpr int NF = Q::RPW + 2, NM = 2 * Q::RPW;
+                auto load_frag = [&](int step, int f, uint4 (&af_)[Q::RPW], uint4 (&bf_)[2]) __attribute__((always_inline)) {
+                    const int tap = step >> 1, ks = step & 1, kh = tap / 3, kw = tap % 3;
+                    // order B0, A0, B1, A1, A2, ...: the first MFMA of the next step needs (A0, B0)
+                    if (f == 0 || f == 2) bf_[f >> 1] = *(const uint4*)(lds + b_lane[ks] + (tap * 64 + 32 * (f >> 1)) * 64);
+                    else {
+                        const int mi = f == 1 ? 0 : f - 2;
+                        af_[mi] = *(const uint4*)(lds + a_lane[kw][ks] + ((mi + kh) * K::HALO_W + kw) * 64);
+                    }
+                };
+                const unsigned kill = more ? 0u : kWuOOB;
 #pragma unroll
-                for (int mi = 0; mi < Q::RPW; ++mi)
+                for (int f = 0; f < NF; ++f) load_frag(0, f, af[0], bf[0]);
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) mma(acc[mi][ni], bf[cur][ni], af[cur][mi]);   // D^T = W * X^T
+                for (int step = 0; step < 18; ++step) {
+                    const int cur = step & 1;
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        mma(acc[m >> 1][m & 1], bf[cur][m & 1], af[cur][m >> 1]);
+                        if (step + 1 < 18 && m < NF) load_frag(step + 1, m, af[cur ^ 1], bf[cur ^ 1]);
+                        // 20 pieces, two behind the last MFMA of steps 0..9 (four per step over steps 0..4 measured slower)
+                        if (m == NM - 1 && 2 * step < Q::NP) {
+                            issue_piece(2 * step, c1, nxt, kill);
+                            if (2 * step + 1 < Q::NP) issue_piece(2 * step + 1, c1, nxt, kill);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
             buf = nxt;
             WU_STAMP(t_comp);
@@ -243,15 +313,17 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         // A wave that finishes its MFMAs early does this while its SIMD partner still computes.
         WU_STAMP(t_epi_b1);
         const size_t img_pix = (size_t)n * a.H * a.W;
-        auto epi_store = [&](auto act_tag) __attribute__((always_inline)) {
-            constexpr int ACT = decltype(act_tag)::value;
+        // Specialised per (activation, gate) pair -- selected once per tile -- so the body is straight packed arithmetic:
+        // v_pk_add_f32 bias, v_cvt_pk_bf16_f32, ReLU as v_pk_max_i16 on the packed pair (ReLU commutes with the monotonic
+        // rounding), the ReLU gate as packed 16-bit integer masks; no per-element compare / select chains.
+        auto epi_store = [&](auto act_tag, auto eg_tag) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(act_tag)::value, EG = decltype(eg_tag)::value;
 #pragma unroll
             for (int mi = 0; mi < Q::RPW; ++mi) {
                 const int oh = oh0 + Q::RPW * wave + mi, ow = ow0 + l31;
                 const bool ok = oh < a.H && ow < a.W;
                 const size_t pix = img_pix + (size_t)(oh * a.W + ow);
                 bf16_t* yp = a.y + pix * a.ldy + co0 + 8 * lh;
-                const bf16_t* ep = a.egate ? a.egate + pix * a.ldegate + co0 + 8 * lh : nullptr;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -261,28 +333,49 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                         for (int h = 0; h < 2; ++h) {
                             const float4 bv = bvq[ni][g + h];
                             const int r0 = 4 * (g + h);
-                            o[h][0] = pack_bf16x2(act_apply(acc[mi][ni][r0 + 0] + bv.x, ACT), act_apply(acc[mi][ni][r0 + 1] + bv.y, ACT));
-                            o[h][1] = pack_bf16x2(act_apply(acc[mi][ni][r0 + 2] + bv.z, ACT), act_apply(acc[mi][ni][r0 + 3] + bv.w, ACT));
+                            f32x2_t v0 = f32x2_t{acc[mi][ni][r0 + 0], acc[mi][ni][r0 + 1]} + f32x2_t{bv.x, bv.y};
+                            f32x2_t v1 = f32x2_t{acc[mi][ni][r0 + 2], acc[mi][ni][r0 + 3]} + f32x2_t{bv.z, bv.w};
+                            if (ACT == WU_ACT_LEAKY) {      // max(v, 0.2 v)
+                                const f32x2_t s0_ = v0 * 0.2f, s1_ = v1 * 0.2f;
+                                v0 = f32x2_t{fmaxf(v0.x, s0_.x), fmaxf(v0.y, s0_.y)};
+                                v1 = f32x2_t{fmaxf(v1.x, s1_.x), fmaxf(v1.y, s1_.y)};
+                            }
+                            o[h][0] = pack_bf16x2(v0.x, v0.y);
+                            o[h][1] = pack_bf16x2(v1.x, v1.y);
+                            if (ACT == WU_ACT_RELU) { o[h][0] = relu_bf16x2(o[h][0]); o[h][1] = relu_bf16x2(o[h][1]); }
                         }
                         // vdst = group g, src = group g+1 (cdna guide T21)
                         const auto s0 = __builtin_amdgcn_permlane32_swap(o[0][0], o[1][0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(o[0][1], o[1][1], false, false);
                         uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                        if (ok) {
-                            const int cofs = 32 * ni + 8 * g;
-                            if (ep) v = gate16<bf16_t>(v, *(const uint4*)(ep + cofs), a.egate_act);
-                            *(uint4*)(yp + cofs) = v;
+                        if (EG != WU_ACT_NONE) {
+                            const uint4 yv = egv[mi][ni][g >> 1];
+                            if (EG == WU_ACT_RELU) {
+                                v.x = relu_gate_bf16x2(v.x, yv.x); v.y = relu_gate_bf16x2(v.y, yv.y);
+                                v.z = relu_gate_bf16x2(v.z, yv.z); v.w = relu_gate_bf16x2(v.w, yv.w);
+                            } else {
+                                v = gate16<bf16_t>(v, yv, WU_ACT_LEAKY);
+                            }
                         }
+                        if (ok) *(uint4*)(yp + 32 * ni + 8 * g) = v;
                     }
             }
         };
-        if (a.act == WU_ACT_RELU) epi_store(std::integral_constant<int, WU_ACT_RELU>{});
-        else if (a.act == WU_ACT_LEAKY) epi_store(std::integral_constant<int, WU_ACT_LEAKY>{});
-        else epi_store(std::integral_constant<int, WU_ACT_NONE>{});
+        using A0 = std::integral_constant<int, WU_ACT_NONE>;
+        using A1 = std::integral_constant<int, WU_ACT_RELU>;
+        using A2 = std::integral_constant<int, WU_ACT_LEAKY>;
+        if (a.egate) {                     // host guarantees act == NONE with a gate (conv_v2_eligible)
+            if (a.egate_act == WU_ACT_RELU) epi_store(A0{}, A1{});
+            else if (a.egate_act == WU_ACT_LEAKY) epi_store(A0{}, A2{});
+            else epi_store(A0{}, A0{});
+        } else if (a.act == WU_ACT_RELU) epi_store(A1{}, A0{});
+        else if (a.act == WU_ACT_LEAKY) epi_store(A2{}, A0{});
+        else epi_store(A0{}, A0{});
         // interior tile: every lane issued all NST stores (the counted vmcnt wait at the next chunk top relies on it)
         stores_in_flight = oh0 + K::TH <= a.H && ow0 + K::TW <= a.W;
         WU_STAMP(t_epi_s);
     }
+    if (NW == 4) dma_wait_all();     // the killed pieces of the last chunk still write LDS: drain before the LDS is released
     if (a.dbg && lane == 0) {
         unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
         d[0] = t_wait; d[1] = t_comp; d[2] = __builtin_readcyclecounter() - t_k0; d[3] = __builtin_amdgcn_s_memrealtime() - t_r0;   // in-kernel clock = d2 / d3 * 100 MHz
@@ -319,7 +412,10 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
         (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (g_wu_opt[WU_OPT_CONV_V2] == 2) hipLaunchKernelGGL(conv3x3_mfma_v2_kernel<4>, dim3((int)grid), dim3(256), 2 * K::BUF, s, a);
+    // one wave per SIMD with 8 accumulators pays off once a tile has >= 8 chunks (fewer LDS reads per MFMA, no intra-SIMD
+    // skew); with few chunks per tile its un-overlapped epilogue costs more than that.  option 0: 1 = auto, 2 = always 4, 3 = always 8
+    const int mode = g_wu_opt[WU_OPT_CONV_V2];
+    if (mode == 2 || (mode == 1 && Cin >= 256)) hipLaunchKernelGGL(conv3x3_mfma_v2_kernel<4>, dim3((int)grid), dim3(256), 2 * K::BUF, s, a);
     else hipLaunchKernelGGL(conv3x3_mfma_v2_kernel<8>, dim3((int)grid), dim3(512), 2 * K::BUF, s, a);
     return 0;
 }
