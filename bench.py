@@ -92,7 +92,7 @@ def main():
 
     import cunet
     from wu import _lib
-    from wu.ddp import GradBucketReducer
+    from wu.ddp import GradBucketReducer, ready_order
 
     torch.manual_seed(0)                       # same random-init weights on every rank
     net = cunet.Conditional_UNet(5, precision=a.precision).to(dev)
@@ -118,7 +118,9 @@ def main():
     else:
         net.train()                            # Dropout(0.3) active, as in training (cunet.py:28)
         params = list(net.parameters())
-        reducer = GradBucketReducer(params, bucket_mb=12.0) if use_ddp else None
+        # buckets in gradient-ready order, filled from inside the fused backward: all but the last small bucket's
+        # all-reduce runs beside the remaining conv kernels
+        reducer = GradBucketReducer(ready_order(net), bucket_mb=12.0, ready_order=True).attach(net) if use_ddp else None
         opt = torch.optim.Adam(params, lr=1e-4, betas=(0.0, 0.999), weight_decay=1e-4 / 20, fused=True)   # t_cls_train.py:184
 
     def step():

@@ -79,6 +79,99 @@ def test_bucketed_allreduce_world2():
     assert sorted(full0) == list(range(nb)) and log0 == log1
 
 
+class _SinkLinear(torch.autograd.Function):
+    """Stand-in for the fused cUNet node: a two-layer MLP as ONE autograd node whose backward, when a reducer is attached,
+    accumulates each layer's weight gradient straight into the bucket views and announces it (wu.unet_graph.UNetFn does the
+    same with its HIP weight-gradient kernels) -- and returns None for those parameters."""
+
+    @staticmethod
+    def forward(ctx, sink, x, w1, w2):
+        h = torch.tanh(x @ w1.t())
+        ctx.save_for_backward(x, w1, w2, h)
+        ctx.sink, ctx.P = sink, (w1, w2)
+        return h @ w2.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w1, w2, h = ctx.saved_tensors
+        sink, (p1, p2) = ctx.sink, ctx.P
+        order = []
+        dw2 = g.t() @ h
+        gh = (g @ w2) * (1 - h * h)
+        dw1 = gh.t() @ x
+        if sink is None:
+            return None, None, dw1, dw2
+        p2.grad.add_(dw2); sink.grad_written(p2)        # layer 2 is ready first
+        p1.grad.add_(dw1); sink.grad_written(p1)
+        return None, None, None, None
+
+
+def _sink_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "weather-unet_amd"))
+    from wu.ddp import GradBucketReducer, shard_batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(5)
+        w1 = torch.nn.Parameter(torch.randn(300, 6))
+        w2 = torch.nn.Parameter(torch.randn(2, 300))
+        tail = torch.nn.Linear(2, 1)                   # gradients through ordinary autograd hooks, ready BEFORE the node's
+        # ready order: tail (autograd reaches it first), then w2, w1; tiny buckets -> one parameter each
+        red = GradBucketReducer(list(tail.parameters()) + [w2, w1], bucket_mb=1e-4, ready_order=True)
+        torch.manual_seed(123)
+        x, y = torch.randn(8, 6), torch.randn(8, 1)
+        xs, ys = shard_batch(x, rank, world), shard_batch(y, rank, world)
+        for _ in range(2):
+            red.zero_grad()
+            out = tail(_SinkLinear.apply(red, xs, w1, w2))
+            torch.mean((out - ys) ** 2).backward()
+            log = list(red.launch_log)
+            red.finalize()
+        q.put((rank, [p.grad.detach().numpy().copy() for p in (w1, w2, tail.weight, tail.bias)], log, len(red.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_direct_write_sink_world2():
+    """The fused-node path: gradients written into bucket views from inside one autograd node, buckets launched in ready
+    order while that node is still running, result == single-process gradient of the full batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sink_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import numpy as np
+    (_, g0, log0, nb), (_, g1, log1, _) = res
+    for a, b in zip(g0, g1):
+        assert np.array_equal(a, b)
+    torch.manual_seed(5)
+    w1 = torch.nn.Parameter(torch.randn(300, 6))
+    w2 = torch.nn.Parameter(torch.randn(2, 300))
+    tail = torch.nn.Linear(2, 1)
+    torch.manual_seed(123)
+    x, y = torch.randn(8, 6), torch.randn(8, 1)
+    torch.mean((tail(_SinkLinear.apply(None, x, w1, w2)) - y) ** 2).backward()
+    for g, p in zip(g0, (w1, w2, tail.weight, tail.bias)):
+        assert torch.allclose(torch.from_numpy(g), p.grad, atol=1e-5), (torch.from_numpy(g) - p.grad).abs().max()
+    assert nb == 3 and log0 == [0, 1, 2] and log1 == log0           # every bucket launched during backward, in ready order
+
+
+def test_ready_order_covers_all_parameters():
+    sys.path.insert(0, os.path.join(ROOT, "weather-unet_amd"))
+    import cunet
+    from wu.ddp import ready_order
+    net = cunet.Conditional_UNet(5)
+    order = ready_order(net)
+    assert {id(p) for p in order} == {id(p) for p in net.parameters() if p.requires_grad} and len(order) == len(set(map(id, order)))
+    assert order[0] is net.conv_last.weight and order[2] is net.dconv_up1[2].weight
+
+
 def test_reducer_single_process_noop():
     sys.path.insert(0, os.path.join(ROOT, "weather-unet_amd"))
     from wu.ddp import GradBucketReducer

@@ -434,3 +434,41 @@ def test_full_size_properties():
         a, b = g16[k].double().reshape(-1), g32[k].double().reshape(-1)
         cos = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
         assert cos >= 0.97, f"{k}: cosine {cos}"
+
+
+def test_fused_backward_gradient_sink():
+    """wu.ddp.GradBucketReducer.attach(): the fused node accumulates dW / db straight into the reducer's bucket views and
+    announces them layer by layer (the all-reduce of a full bucket then overlaps the rest of backward).  Single process:
+    the collectives are no-ops, the gradients must equal the ordinary autograd path bit for bit, buckets must have been
+    launched (in order) before backward returned, and a second backward without zero_grad must ACCUMULATE."""
+    from wu.ddp import GradBucketReducer, ready_order
+    nc = 5
+    net = _make_g(nc, 4, "bf16").train()
+    net.dropout_seed = 9
+    x, c = (t.to(DEV) for t in O.make_inputs(2, 64, nc, 4, True))
+
+    def run():
+        out = net(x, c)
+        torch.mean(torch.abs(out - x)).backward()
+
+    for p in net.parameters():
+        p.grad = None
+    run()
+    ref = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    red = GradBucketReducer(ready_order(net), bucket_mb=2.0, ready_order=True).attach(net)
+    red.zero_grad()
+    run()
+    log = list(red.launch_log)
+    red.finalize()
+    assert len(red.buckets) >= 4 and log == list(range(len(log))) and len(log) >= len(red.buckets) - 1
+    for k, p in net.named_parameters():
+        if k in ref:
+            if k.startswith(("dconv_down1.0", "conv_last")):       # fp32 atomics (see test_full_size_properties)
+                assert torch.allclose(p.grad, ref[k], rtol=1e-4, atol=1e-7), k
+            else:
+                assert torch.equal(p.grad, ref[k]), k
+    run()                                                # no zero_grad: accumulate
+    red.finalize()
+    for k in ("dconv_up1.2.weight", "dconv_down4.0.bias", "adain2.fc_std.weight" if "adain2.fc_std.weight" in ref else "dconv_up3.0.weight"):
+        assert torch.allclose(dict(net.named_parameters())[k].grad, 2 * ref[k], rtol=1e-5, atol=1e-8), k
+    net.grad_sink = None

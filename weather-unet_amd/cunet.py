@@ -65,6 +65,7 @@ class Conditional_UNet(nn.Module):
         self.set_precision(precision)
         self.dropout_seed = None     # int -> reproducible dropout masks (tests); None -> fresh seed per call
         self.fused = True            # one autograd node for the whole net (wu/unet_graph.py); False = per-layer Functions
+        self.grad_sink = None        # wu.ddp.GradBucketReducer.attach(): overlap gradient all-reduce with the fused backward
 
     def set_precision(self, precision):
         precision_code(precision)

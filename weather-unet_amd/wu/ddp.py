@@ -24,14 +24,20 @@ class GradBucketReducer:
     """Bucketed, overlapped gradient averaging.
 
     ``params``     parameters in registration (forward) order; buckets are formed over the reversed list
+                   (``ready_order=True``: the list already IS the order in which gradients become ready)
     ``bucket_mb``  target bucket size; the last-registered (first-ready) parameters fill bucket 0
+
+    Gradients reach a bucket either through autograd (post-accumulate hooks) or, for the fused cUNet node whose
+    gradients would otherwise all surface at once when the node returns, directly: ``attach(net)`` makes the node write
+    each layer's dW / db into the bucket views the moment its weight-gradient kernel is enqueued and call
+    ``grad_written`` -- a full bucket's all-reduce then runs beside the REST of the backward pass.
 
     Usage per step:  ``reducer.zero_grad(); loss.backward(); reducer.finalize(); optimizer.step()``.
     ``param.grad`` is a view into its bucket's flat buffer for the lifetime of the reducer (do not call
     ``optimizer.zero_grad(set_to_none=True)``; use ``reducer.zero_grad()``).
     """
 
-    def __init__(self, params, bucket_mb=12.0, group=None, broadcast=True):
+    def __init__(self, params, bucket_mb=12.0, group=None, broadcast=True, ready_order=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
@@ -43,7 +49,7 @@ class GradBucketReducer:
         limit = int(bucket_mb * (1 << 20) / 4)
         self.buckets = []          # list of dict(flat, params, pending, work)
         cur, cur_n = [], 0
-        for p in reversed(self.params):
+        for p in (self.params if ready_order else reversed(self.params)):
             if cur and cur_n + p.numel() > limit:
                 self.buckets.append(self._make_bucket(cur, dev))
                 cur, cur_n = [], 0
@@ -112,6 +118,19 @@ class GradBucketReducer:
         if b["pending"] == 0:
             self._launch(bi)
 
+    def grad_written(self, p):
+        """A producer accumulated this step's gradient of `p` straight into ``p.grad`` (the bucket view) on the current
+        stream and returns None for it to autograd: same bookkeeping as the autograd hook."""
+        self._on_grad_ready(p)
+
+    def owns(self, params):
+        return all(p in self._bucket_of for p in params)
+
+    def attach(self, net):
+        """Route the fused cUNet node's weight gradients through ``grad_written`` (see class docstring)."""
+        net.grad_sink = self
+        return self
+
     def finalize(self):
         """Launch the buckets that never filled (parameters unused in this backward, e.g. AdaIN.emb,
         utils.py:32), wait for every collective, and finish the mean."""
@@ -128,6 +147,22 @@ class GradBucketReducer:
         for h in self._hooks:
             h.remove()
         self._hooks.clear()
+
+
+def ready_order(net):
+    """Parameters of a Conditional_UNet in the order their gradients become ready in the fused backward: head and decoder
+    convs first, then the encoder back to front; everything autograd produces AFTER the node returns (AdaIN style layers,
+    cunet.py:56-58 / utils.py:41-46) last, so only one small bucket is left to reduce after the last conv kernel."""
+    convs = []
+    for name in ("conv_last", "dconv_up1", "dconv_up2", "dconv_up3", "dconv_down4", "dconv_down3", "dconv_down2", "dconv_down1"):
+        mod = getattr(net, name)
+        if name == "conv_last":
+            convs.extend(mod.parameters())
+        else:        # backward visits the second conv of a block before the first
+            convs.extend(list(mod[2].parameters()) + list(mod[0].parameters()))
+    seen = {id(p) for p in convs}
+    rest = [p for p in net.parameters() if id(p) not in seen]
+    return [p for p in convs + rest if p.requires_grad]
 
 
 def broadcast_buffers(module, src=0, group=None):

@@ -22,7 +22,7 @@ import torch.nn as nn
 import ops
 from cunet import Conditional_UNet
 from disc import SNDisc
-from wu.ddp import GradBucketReducer, broadcast_buffers, is_distributed
+from wu.ddp import GradBucketReducer, broadcast_buffers, is_distributed, ready_order
 
 
 class StandInEstimator(nn.Module):
@@ -63,7 +63,7 @@ class WeatherTransferStep:
         self.ddp = is_distributed() if ddp is None else ddp
         self.g_red = self.d_red = None
         if self.ddp:
-            self.g_red = GradBucketReducer(list(self.inference.parameters()), bucket_mb=12.0)
+            self.g_red = GradBucketReducer(ready_order(self.inference), bucket_mb=12.0, ready_order=True).attach(self.inference)
             self.d_red = GradBucketReducer(list(self.discriminator.parameters()), bucket_mb=12.0)
             broadcast_buffers(self.discriminator)      # SN weight_u / weight_v identical on every rank
 

@@ -28,7 +28,7 @@ def _new(n, c, h, w, dt, dev):
 class UNetFn(Function):
     @staticmethod
     def forward(ctx, meta, x, ys3, ym3, ys2, ym2, ys1, ym1, *params):
-        code, p_drop, seeds, eps, packed = meta
+        code, p_drop, seeds, eps, packed, sink = meta
         dt, dev = torch_dtype(code), x.device
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
@@ -88,6 +88,10 @@ class UNetFn(Function):
             ctx.pk_dgrad = {k: v[1] for k, v in pk.items()}
             ctx.mbits = (mb3, mb2, mb1)
             ctx.meta = (code, p_drop, seeds, [tuple(p.shape) for p in P])
+            # gradient sink (wu.ddp.GradBucketReducer.attach): weight gradients are accumulated straight into the parameters'
+            # bucket-view .grad and announced layer by layer, so bucket all-reduces overlap the rest of this backward
+            ctx.sink = sink if (sink is not None and sink.enabled and sink.owns(P)) else None
+            ctx.sink_params = P if ctx.sink is not None else None
         return out
 
     @staticmethod
@@ -101,22 +105,36 @@ class UNetFn(Function):
         n, _, h, w = x.shape
         f32 = dict(dtype=torch.float32, device=dev)
         grads = {}
+        sink, SP = ctx.sink, ctx.sink_params
+
+        def grad_bufs(iw):
+            """(dw, db, accumulate) for parameters iw, iw+1: fresh tensors handed to autograd, or the bucket views."""
+            if sink is None:
+                return torch.empty(shapes[iw], **f32), torch.empty(shapes[iw + 1], **f32), False
+            return SP[iw].grad, SP[iw + 1].grad, True
+
+        def done(key, iw, dw, db):
+            if sink is None:
+                grads[key] = (dw, db)
+            else:
+                grads[key] = (None, None)
+                sink.grad_written(SP[iw])
+                sink.grad_written(SP[iw + 1])
 
         def wgrad(name, j, xin, gy):
-            dw = torch.empty(shapes[4 * BLOCKS.index(name) + j], **f32)
-            db = torch.empty(shapes[4 * BLOCKS.index(name) + j + 1], **f32)
-            K.conv3x3_wgrad(xin, gy, dw, db)
-            grads[(name, j)] = (dw, db)
+            iw = 4 * BLOCKS.index(name) + j
+            dw, db, acc = grad_bufs(iw)
+            K.conv3x3_wgrad(xin, gy, dw, db, accumulate=acc)
+            done((name, j), iw, dw, db)
 
         def block_bwd(name, xin, mid, g_out_gated, need_dx=True):
             """r_double_conv backward given the PRE-GATED gradient of its output; returns dL/d(xin) (ungated)."""
             wgrad(name, 2, mid, g_out_gated)
             g_mid = K.conv3x3(g_out_gated, wd[name + ".2"], None, _new(*mid.shape, dt, dev), egate=mid, egate_act=RELU)
             if name == "dconv_down1":
-                dw = torch.empty(shapes[0], **f32)
-                db = torch.empty(shapes[1], **f32)
-                K.conv3x3_c3_wgrad(xin, g_mid, dw, db, 1, code)
-                grads[(name, 0)] = (dw, db)
+                dw, db, acc = grad_bufs(0)
+                K.conv3x3_c3_wgrad(xin, g_mid, dw, db, 1, code, accumulate=acc)
+                done((name, 0), 0, dw, db)
                 return g_mid
             wgrad(name, 0, xin, g_mid)
             if not need_dx:
@@ -126,9 +144,9 @@ class UNetFn(Function):
         # head: dx gated by ReLU'(u1b)
         gout = gout.float().contiguous()
         g_u1b = _new(n, 64, h, w, dt, dev)
-        dw_last = torch.empty((3, 64), **f32)
-        db_last = torch.empty((3,), **f32)
-        K.conv1x1_tanh_bwd(gout, out, u1b, w3c, g_u1b, dw_last, db_last, x_gate_act=RELU)
+        dw_last, db_last, acc_last = grad_bufs(28)
+        K.conv1x1_tanh_bwd(gout, out, u1b, w3c, g_u1b, dw_last.view(3, 64), db_last, x_gate_act=RELU, accumulate=acc_last)
+        done(("conv_last", 0), 28, dw_last, db_last)
 
         # decoder level 1
         g_cat1 = block_bwd("dconv_up1", cat1, u1a, g_u1b)
@@ -162,8 +180,9 @@ class UNetFn(Function):
         for name in BLOCKS:
             for j in (0, 2):
                 flat.extend(grads[(name, j)])
-        flat.append(dw_last.view(shapes[28]))
-        flat.append(db_last)
+        gl = grads[("conv_last", 0)]
+        flat.append(gl[0].view(shapes[28]) if gl[0] is not None else None)
+        flat.append(gl[1])
         return (None, dx, dys3, dym3, dys2, dym2, dys1, dym1, *flat)
 
 
@@ -182,5 +201,5 @@ def unet_forward(net, x, c):
     params.extend((net.conv_last.weight, net.conv_last.bias))
     p = net.dropout.p if net.training else 0.0
     seeds = tuple(net._next_seed(k) for k in (3, 2, 1))
-    meta = (code, float(p), seeds, float(net.adain3.eps), packed)
+    meta = (code, float(p), seeds, float(net.adain3.eps), packed, getattr(net, "grad_sink", None))
     return UNetFn.apply(meta, x, *styles, *params)
