@@ -1,7 +1,7 @@
 // Spectral normalisation of a conv weight (torch.nn.utils.spectral_norm, nets.py:28-31): one power iteration
 //   v <- normalize(W^T u),  u <- normalize(W v),  sigma = u . (W v),  W_eff = W / sigma
 // and its backward  dW = G / sigma - (<G, W> / sigma^2) u v^T   (u, v are constants of the graph, as in torch).
-// The reference runs this through ~25 tiny torch kernels per layer and forward; here it is 4 launches forward and 2
+// The reference runs this through ~25 tiny torch kernels per layer and forward; here it is 5 launches forward and 2
 // backward, all deterministic (fixed-order block reductions), W (rows x cols, fp32, OIHW flattened) read twice.
 #include "wu_common.h"
 
@@ -9,15 +9,36 @@ namespace {
 
 constexpr int kPartMax = 1024;   // max partial-sum slots in scratch
 
-// v_raw[j] = sum_i W[i][j] u[i]; per-block partial of sum_j v_raw[j]^2 -> part[blockIdx.x]
-__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ w, const float* __restrict__ u, float* __restrict__ v_raw,
-                                                      float* __restrict__ part, int rows, int cols) {
+constexpr int kRowGroup = 32;    // rows per partial of W^T u
+
+// W^T u in two deterministic stages (one thread per column walking ALL rows left 18 workgroups on a 256-CU chip):
+//   A: pv[g][j] = sum_{i in row group g} W[i][j] u[i]                       grid (cols/256, rows/32)
+//   B: v_raw[j] = sum_g pv[g][j];  part[blockIdx.x] = sum_j v_raw[j]^2      grid (cols/256)
+__global__ __launch_bounds__(256) void sn_wt_u_partial_kernel(const float* __restrict__ w, const float* __restrict__ u, float* __restrict__ pv,
+                                                              int rows, int cols) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    const int i0 = blockIdx.y * kRowGroup, i1 = min(rows, i0 + kRowGroup);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = i0;
+    for (; i + 4 <= i1; i += 4) {
+        s0 += w[(size_t)i * cols + j] * u[i];
+        s1 += w[(size_t)(i + 1) * cols + j] * u[i + 1];
+        s2 += w[(size_t)(i + 2) * cols + j] * u[i + 2];
+        s3 += w[(size_t)(i + 3) * cols + j] * u[i + 3];
+    }
+    for (; i < i1; ++i) s0 += w[(size_t)i * cols + j] * u[i];
+    pv[(size_t)blockIdx.y * cols + j] = (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(256) void sn_wt_u_fold_kernel(const float* __restrict__ pv, int groups, float* __restrict__ v_raw,
+                                                           float* __restrict__ part, int cols) {
     __shared__ float red[256];
     const int j = blockIdx.x * 256 + threadIdx.x;
     float s = 0.f;
-    if (j < cols)
-        for (int i = 0; i < rows; ++i) s += w[(size_t)i * cols + j] * u[i];
-    if (j < cols) v_raw[j] = s;
+    if (j < cols) {
+        for (int g = 0; g < groups; ++g) s += pv[(size_t)g * cols + j];
+        v_raw[j] = s;
+    }
     red[threadIdx.x] = j < cols ? s * s : 0.f;
     __syncthreads();
     for (int m = 128; m > 0; m >>= 1) {
@@ -94,10 +115,19 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(const float* __restrict__ g
     }
     if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
-__global__ void sn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ sigma,
+__global__ __launch_bounds__(256) void sn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ sigma,
                               const float* __restrict__ part, int nparts, float* __restrict__ dw, int rows, int cols) {
-    float dot = 0.f;
-    for (int k = 0; k < nparts; ++k) dot += part[k];
+    // <G, W>: the per-block partials summed by the whole workgroup in a fixed tree (every thread used to walk all of them)
+    __shared__ float red[256];
+    float ps = 0.f;
+    for (int k = threadIdx.x; k < nparts; k += 256) ps += part[k];
+    red[threadIdx.x] = ps;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+        if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    const float dot = red[0];
     const float inv = sigma[1], c = dot * inv * inv;          // <G,W> / sigma^2
     const long long n = (long long)rows * cols;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -108,7 +138,9 @@ __global__ void sn_bwd_kernel(const float* __restrict__ g, const float* __restri
 
 }  // namespace
 
-extern "C" size_t wu_spectral_norm_scratch_floats(int rows, int cols) { return (size_t)cols + rows + 2 * kPartMax; }
+extern "C" size_t wu_spectral_norm_scratch_floats(int rows, int cols) {
+    return (size_t)cols + rows + 2 * kPartMax + (size_t)cdiv(rows, kRowGroup) * cols;
+}
 
 // u (rows), v (cols): power-iteration buffers, updated in place when power_iter != 0.  sigma_out[0] = sigma,
 // sigma_out[1] = 1/sigma.  w_eff (may be NULL) receives W / sigma.  scratch: wu_spectral_norm_scratch_floats().
@@ -122,7 +154,10 @@ extern "C" int wu_spectral_norm_fwd(const float* w, int rows, int cols, float* u
     const int nb = cdiv(cols, 256);
     WU_REQUIRE(nb <= kPartMax, "spectral_norm_fwd: cols too large");
     if (power_iter) {
-        hipLaunchKernelGGL(sn_wt_u_kernel, dim3(nb), dim3(256), 0, s, w, u, v_raw, part, rows, cols);
+        float* pv = part + 2 * kPartMax;
+        const int groups = cdiv(rows, kRowGroup);
+        hipLaunchKernelGGL(sn_wt_u_partial_kernel, dim3(nb, groups), dim3(256), 0, s, w, u, pv, rows, cols);
+        hipLaunchKernelGGL(sn_wt_u_fold_kernel, dim3(nb), dim3(256), 0, s, pv, groups, v_raw, part, cols);
         hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, s, w, v_raw, part, nb, 1, eps, v, u_raw, rows, cols);
     } else {
         hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, s, w, v, part, 0, 0, eps, (float*)nullptr, u_raw, rows, cols);
