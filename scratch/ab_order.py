@@ -17,11 +17,11 @@ for name, ci, co, s in layers:
     wf, wd = K.pack_conv3x3(w, 1); bias = torch.zeros(co, device=dev)
     y = empty_nhwc(B, co, s, s, torch.bfloat16, dev)
     gf = 2 * B * s * s * 9 * ci * co / 1e9
-    res = {0: [], 1: [], 2: []}; outs = {}
+    res = {0: [], 1: []}; outs = {}
     for rnd in range(7):
-        for order in (0, 1, 2):
-            _lib.call('wu_set_option', 6, order)
+        for order in (0, 1):
+            _lib.call('wu_set_option', 7, order)
             res[order].append(run(lambda: K.conv3x3(x, wf, bias, y, 1, 1)))
             if rnd == 0: outs[order] = y.clone()
-    print(f"{name:8s} {ci:4d}->{co:4d} @{s:3d}: prio-off {statistics.median(res[0]):7.1f} us ({gf/statistics.median(res[0]):.3f} PF)   prio-waves4-7 {statistics.median(res[1]):7.1f} us ({gf/statistics.median(res[1]):.3f} PF)  alternating {statistics.median(res[2]):7.1f} us ({gf/statistics.median(res[2]):.3f} PF)  equal {torch.equal(outs[0], outs[1])}")
-_lib.call('wu_set_option', 6, 1)
+    print(f"{name:8s} {ci:4d}->{co:4d} @{s:3d}: contiguous {statistics.median(res[0]):7.1f} us ({gf/statistics.median(res[0]):.3f} PF)   strided {statistics.median(res[1]):7.1f} us ({gf/statistics.median(res[1]):.3f} PF)  equal {torch.equal(outs[0], outs[1])}")
+_lib.call('wu_set_option', 7, 0)

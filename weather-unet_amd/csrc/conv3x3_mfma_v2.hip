@@ -43,7 +43,7 @@ struct V2Args {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; const bf16_t* egate;
     int ldx, ldy, ldegate, egate_act;
     int N, H, W, Cin, Cout, act;
-    int tiles_x, tiles_y, cout_tiles, ntiles, ct_slowest, prio_mode;
+    int tiles_x, tiles_y, cout_tiles, ntiles, ct_slowest, prio_mode, strided;
     unsigned long long* dbg;     // diagnostic: per-workgroup phase cycle sums (NULL in production)
 };
 
@@ -77,8 +77,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
 
     // ---- persistent workgroup: a contiguous range of (n, ty, tx, cout-tile) items, cout-tile fastest ----
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int t_begin = (int)((long long)a.ntiles * wg / gridDim.x);
-    const int t_end = (int)((long long)a.ntiles * (wg + 1) / gridDim.x);
+    // contiguous: this workgroup walks tiles [t_begin, t_end) (its own consecutive cout tiles re-read one halo);
+    // strided:    tiles wg, wg + grid, ...: at any moment the 32 workgroups of an XCD hold 32 CONSECUTIVE tile ids = a few pixel
+    //             tiles x all their cout tiles, so the halo re-reads of the cout tiles are concurrent hits in that XCD's L2
+    const int t_step = a.strided ? (int)gridDim.x : 1;
+    const int t_begin = a.strided ? wg : (int)((long long)a.ntiles * wg / gridDim.x);
+    const int t_end = a.strided ? a.ntiles : (int)((long long)a.ntiles * (wg + 1) / gridDim.x);
     if (t_begin >= t_end) return;
 
     // ---- tile-invariant per-lane DMA byte offsets (wu_common.h, wu_dma16b): LDS slot i = piece*64 + lane ----
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
 #pragma unroll
     for (int j = 0; j < Q::NP; ++j) issue_piece(j, 0, 0);
 
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    for (int tile = t_begin; tile < t_end; tile += t_step) {
         // accumulators are kept TRANSPOSED (rows = cout, cols = pixels: the weight fragment is the MFMA A operand):
         // a lane then owns 4 consecutive channels of one pixel per register quad -> 8-byte epilogue writes
         f32x16_t acc[Q::RPW][2];
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
             const int nxt = buf ^ 1;
             // what to fetch while computing this chunk: the next chunk of this tile, or chunk 0 of the next tile
             const bool last = c + 1 == nchunks;
-            const bool more = !last || tile + 1 < t_end;
+            const bool more = !last || tile + t_step < t_end;
             const int c1 = last ? 0 : (c + 1) * 32;
             // this wave's pieces of the current chunk must have landed.  Right after an interior tile's epilogue the 8
             // output stores are the YOUNGEST vector-memory ops and every DMA piece is older: vmcnt(8) retires the DMA
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                     for (int g = 0; g < 4; ++g)
                         bvq[ni][g] = a.bias ? *(const float4*)(a.bias + ct_ * 64 + 32 * ni + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (last && more) set_fetch_tile(tile + 1);
+            if (last && more) set_fetch_tile(tile + t_step);
             // the gate values of this tile's outputs are requested at the start of its LAST chunk: they land under the MFMAs
             // instead of stalling every store of the epilogue (out-of-image pixels are clamped, their stores are skipped)
             if (last && a.egate) {
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
     if (a.dbg && lane == 0) {
         unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
         d[0] = t_wait; d[1] = t_comp; d[2] = __builtin_readcyclecounter() - t_k0; d[3] = __builtin_amdgcn_s_memrealtime() - t_r0;   // in-kernel clock = d2 / d3 * 100 MHz
-         d[4] = t_epi_b2; d[5] = t_epi_s; d[6] = (unsigned long long)(t_end - t_begin); d[7] = nchunks;
+         d[4] = t_epi_b2; d[5] = t_epi_s; d[6] = (unsigned long long)((t_end - t_begin + t_step - 1) / t_step); d[7] = nchunks;
     }
 #undef WU_STAMP
 }
@@ -401,6 +405,7 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     a.dbg = (unsigned long long*)g_wu_dbg_ptr;
     a.ct_slowest = g_wu_opt[WU_OPT_CONV_CT_SLOWEST];
     a.prio_mode = g_wu_opt[WU_OPT_CONV_PRIO];
+    a.strided = g_wu_opt[WU_OPT_CONV_STRIDED];
     const long long ntiles = (long long)N * a.tiles_x * a.tiles_y * a.cout_tiles;
     if (ntiles >= (1ll << 31)) return -1;
     a.ntiles = (int)ntiles;

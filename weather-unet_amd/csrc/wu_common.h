@@ -40,6 +40,7 @@ extern void* g_wu_dbg_ptr;
 #define WU_OPT_WGRAD_DMA_INTERLEAVE 4
 #define WU_OPT_C3_ROWS 5
 #define WU_OPT_CONV_PRIO 6
+#define WU_OPT_CONV_STRIDED 7
 
 // ---- profiling hooks (wu_prof.hip) --------------------------------------------------------------
 void wu_prof_pre(int family, hipStream_t s);
