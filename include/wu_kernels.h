@@ -41,11 +41,15 @@ extern "C" {
 
 const char* wu_last_error(void);
 int wu_version(void);
-/* Kernel-variant switches for in-process A/B benchmarking (0: conv LDS-DMA path on/off, 1: persistent tile loop
- * on/off, 2: LDS-DMA wgrad on/off).  Defaults = production choices; results are identical either way. */
+/* Kernel-variant switches for in-process A/B benchmarking.  Defaults = production choices; results are identical either way.
+ *   0: conv LDS-DMA path (0 off = generic template, 1 auto wave shape (default), 2 always 4 waves, 3 always 8 waves)
+ *   1: persistent tile loop on/off      2: LDS-DMA wgrad on/off        3: cout tile slowest in the tile order (default 0)
+ *   4: wgrad DMA issue spread over K-steps (default 1)   5: row-wise thin first conv (default 0)
+ *   6: static priority for the younger wave half (default 1)   7: grid-strided tile assignment (default 1) */
 int wu_set_option(int key, int value);
-/* Diagnostic: device buffer of 256*8*8 uint64 receiving per-wave phase cycle sums of the persistent conv kernel
- * (wait, compute, epilogue barrier/LDS write/barrier/stores, tiles, chunks); NULL (default) disables stamping. */
+/* Diagnostic: device buffer of 256*8*8 uint64 receiving per-wave phase cycle sums of the persistent conv / wgrad kernels
+ * (DMA wait, compute, whole-kernel s_memtime and s_memrealtime deltas -> in-kernel clock, barrier, epilogue, tiles, chunks);
+ * NULL (default) disables stamping. */
 int wu_set_debug_buffer(void* p);
 
 /* ---- weights -------------------------------------------------------------------------------

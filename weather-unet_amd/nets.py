@@ -100,7 +100,7 @@ class SNConv3x3(_Conv3x3Base):
 
 
 def spectral_normalize(weight_orig, u, v, do_power_iteration, eps=1e-12):
-    """torch.nn.utils.spectral_norm.compute_weight.  On the GPU: the fused HIP kernels (4 launches instead of ~25 tiny
+    """torch.nn.utils.spectral_norm.compute_weight.  On the GPU: the fused HIP kernels (5 launches instead of ~25 tiny
     torch kernels); on CPU tensors (module construction / state-dict inspection only): the same arithmetic in torch."""
     if weight_orig.is_cuda:
         return WF.spectral_normalize(weight_orig, u, v, do_power_iteration, eps)
