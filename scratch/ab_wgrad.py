@@ -18,9 +18,9 @@ for name, ci, co, s in layers:
     res = {0: [], 1: []}; outs = {}
     for rnd in range(7):
         for v in (0, 1):
-            _lib.call('wu_set_option', 4, v)
+            _lib.call('wu_set_option', 2, v + 1)
             res[v].append(run(lambda: K.conv3x3_wgrad(x, gy, dw, db)))
             if rnd == 0: outs[v] = (dw.clone(), db.clone())
     rel = ((outs[0][0] - outs[1][0]).norm() / outs[0][0].norm()).item()
-    print(f"{name:6s} {ci:4d}->{co:4d} @{s:3d}: burst {statistics.median(res[0]):7.1f} us ({gf/statistics.median(res[0]):.3f} PF)   interleaved {statistics.median(res[1]):7.1f} us ({gf/statistics.median(res[1]):.3f} PF)  (incl. reduce)  rel diff {rel:.2e}")
-_lib.call('wu_set_option', 4, 1)
+    print(f"{name:6s} {ci:4d}->{co:4d} @{s:3d}: 8 waves {statistics.median(res[0]):7.1f} us ({gf/statistics.median(res[0]):.3f} PF)   4 waves {statistics.median(res[1]):7.1f} us ({gf/statistics.median(res[1]):.3f} PF)  (incl. reduce)  rel diff {rel:.2e}")
+_lib.call('wu_set_option', 2, 1)

@@ -17,6 +17,7 @@
 //  * the tile is fixed at 8 x 32 pixels: every fragment address is lane_base + compile-time immediate, so the
 //    fully unrolled K loop contains no address arithmetic.
 #include <type_traits>
+#include <utility>
 
 #include "wu_common.h"
 #include "wgrad_internal.h"
@@ -30,12 +31,18 @@ struct C {
     static constexpr int HALO_W = 34, HALO_H = TH + 2, HALO_PIX = HALO_W * HALO_H;
     static constexpr int DY_BYTES = P * DY_ROW;          // 32 KiB
     static constexpr int DY_PIECES = DY_BYTES / 1024;    // 32 DMA pieces of 1 KiB
-    static constexpr int NW = 8;                         // waves per workgroup
-    static constexpr int NDY = DY_PIECES / NW;           // 4 DMA pieces per wave
-    static constexpr int NX = ((HALO_PIX * 128 + 1023) / 1024 + NW - 1) / NW;   // 6 (43 pieces carry halo pixels)
-    static constexpr int X_PIECES = NX * NW;             // 48: the 5 pad pieces are out of range for every lane (zeros)
+    static constexpr int X_PIECES = 48;                  // 43 pieces carry halo pixels; the 5 pad pieces are out of range for every lane
     static constexpr int X_BYTES = X_PIECES * 1024;
     static constexpr int BUF = DY_BYTES + X_BYTES;       // 80 KiB; two buffers = all 160 KiB of the CU's LDS
+};
+
+// NW waves per workgroup: 8 (two per SIMD; the wave sets split the even / odd K-steps) or 4 (one per SIMD, both parities)
+template <int NW_> struct CW {
+    static constexpr int NW = NW_;
+    static constexpr int NDY = C::DY_PIECES / NW;        // DMA pieces per wave: 4 / 8
+    static constexpr int NX = C::X_PIECES / NW;          // 6 / 12
+    static constexpr int PARS = NW == 8 ? 1 : 2;         // K-step parities a wave walks itself
+    static constexpr int NG = 8 * PARS;                  // (kk, parity) groups of 5 tap slots per tile
 };
 
 struct W2Args {
@@ -58,51 +65,78 @@ __device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& 
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
 
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) (an 80-step `#pragma unroll` body is
+// beyond the unroller's budget: it stayed rolled, with the fragment ring in scratch memory)
+template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // tap owned by accumulator slot i (0..3) of tap-half HF; slot 4 is the centre tap (4)
 template <int HF> __device__ __forceinline__ constexpr int tap_of(int i) { return i == 4 ? 4 : (HF ? 5 + i : i); }
 
-// One 256-pixel tile = 8 K-step pairs (kk) x 5 tap slots = 40 steps of 2 MFMAs (the centre-tap slot: 1).  Software-pipelined
-// by hand: the X fragment of step s+LA and the dY fragments of the NEXT kk are requested before the MFMAs of step s, so an
-// LDS round trip is always covered by matrix work (the compiler's own order was read-2 / wait / 2 MFMAs, latency exposed).
-template <int HF, typename Issue>
+// One 256-pixel tile = NG (K-step pair kk, parity) groups x 5 tap slots, 2 MFMAs per slot (the centre-tap slot: 1).
+// Software-pipelined by hand: the X fragment of step s+LA and the dY fragments of the NEXT group are requested ahead of the
+// MFMAs that need them, so an LDS round trip is always covered by matrix work (the compiler's own order was read-2 / wait /
+// 2 MFMAs, latency exposed); sched_barrier(0) pins the order.  PARS = 2 (one wave per SIMD): the reads sit BEHIND the MFMA
+// they follow so the matrix pipe is fed first, and the DMA pieces ride behind the second MFMA of a group's first slot.
+template <int HF, int PARS, typename Issue>
 __device__ __forceinline__ void compute_tile(const char* lds, const int (&a_lane)[2], const int (&b_lane)[3], f32x16_t (&acc)[9], Issue&& issue) {
-    auto load_a = [&](int kk, int m) __attribute__((always_inline)) { return tr_frag(lds + a_lane[m] + 32 * kk * C::DY_ROW); };
+    constexpr int NG = 8 * PARS, NS = 5 * NG;
+    auto goff_a = [](int g) { return 32 * (g / PARS) * C::DY_ROW + (g % PARS) * 16 * C::DY_ROW; };
+    auto goff_b = [](int g) { return (g / PARS) * C::HALO_W * 128 + (g % PARS) * 16 * 128; };
+    auto load_a = [&](int g, int m) __attribute__((always_inline)) { return tr_frag(lds + a_lane[m] + goff_a(g)); };
     auto load_b = [&](int s_) __attribute__((always_inline)) {
-        const int kk = s_ / 5, i = s_ % 5;
+        const int g = s_ / 5, i = s_ % 5;
         const int tap = tap_of<HF>(i), kh = tap / 3, kw = tap % 3;
-        return tr_frag(lds + b_lane[kw] + kk * C::HALO_W * 128 + (kh * C::HALO_W + kw) * 128);
+        return tr_frag(lds + b_lane[kw] + goff_b(g) + (kh * C::HALO_W + kw) * 128);
     };
-    constexpr int LA = 2;                 // X-fragment look-ahead in steps (ring of LA + 1); 3 measured the same cycles
+    // X-fragment look-ahead in steps (ring of LA + 1).  Two waves per SIMD: 2 (3 measured the same cycles); a lone wave has
+    // only its own 64 MFMA-cycles per step to cover an LDS round trip: 5
+    constexpr int LA = PARS == 1 ? 2 : 5;
     uint4 af[2][2], bf[LA + 1];
     af[0][0] = load_a(0, 0);
     af[0][1] = load_a(0, 1);
 #pragma unroll
     for (int j = 0; j < LA; ++j) bf[j] = load_b(j);
-#pragma unroll
-    for (int s_ = 0; s_ < 40; ++s_) {
-        const int kk = s_ / 5, i = s_ % 5;
-        // the next tile's DMA pieces are issued inside the first K-steps: their address arithmetic overlaps MFMAs
-        if (i == 0) issue(kk);
-        if (s_ + LA < 40) bf[(s_ + LA) % (LA + 1)] = load_b(s_ + LA);
-        if (kk + 1 < 8 && i == 1) af[(kk + 1) & 1][0] = load_a(kk + 1, 0);
-        if (kk + 1 < 8 && i == 2) af[(kk + 1) & 1][1] = load_a(kk + 1, 1);
-        __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of this step's MFMAs
+    static_for<NS>([&](auto s_tag) __attribute__((always_inline)) {
+        constexpr int s_ = decltype(s_tag)::value;
+        constexpr int g = s_ / 5, i = s_ % 5;
         const uint4 b = bf[s_ % (LA + 1)];
-        if (i < 4) {
-            mma(acc[2 * i], af[kk & 1][0], b);
-            mma(acc[2 * i + 1], af[kk & 1][1], b);
+        if (PARS == 1) {
+            // the next tile's DMA pieces are issued inside the first K-steps: their address arithmetic overlaps MFMAs
+            if (i == 0) issue(g);
+            if (s_ + LA < NS) bf[(s_ + LA) % (LA + 1)] = load_b(s_ + LA);
+            if (g + 1 < NG && i == 1) af[(g + 1) & 1][0] = load_a(g + 1, 0);
+            if (g + 1 < NG && i == 2) af[(g + 1) & 1][1] = load_a(g + 1, 1);
+            __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of this step's MFMAs
+            if (i < 4) {
+                mma(acc[2 * i], af[g & 1][0], b);
+                mma(acc[2 * i + 1], af[g & 1][1], b);
+            } else {
+                mma(acc[8], af[g & 1][HF], b);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         } else {
-            mma(acc[8], af[kk & 1][HF], b);
+            mma(acc[i < 4 ? 2 * i : 8], af[g & 1][i < 4 ? 0 : HF], b);
+            if (s_ + LA < NS) bf[(s_ + LA) % (LA + 1)] = load_b(s_ + LA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < 4) mma(acc[2 * i + 1], af[g & 1][1], b);
+            if (g + 1 < NG && i == 1) af[(g + 1) & 1][0] = load_a(g + 1, 0);
+            if (g + 1 < NG && i == 2) af[(g + 1) & 1][1] = load_a(g + 1, 1);
+            if (i == 0) issue(g);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    });
 }
 
-__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_wgrad_v2_kernel(const W2Args a) {
+    using Q = CW<NW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (DMA base, branches)
-    const int wci = wave & 1, hf = (wave >> 1) & 1, par = wave >> 2;
+    const int wci = wave & 1, hf = (wave >> 1) & 1, par = NW == 8 ? wave >> 2 : 0;
 
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int blocks = a.co_blocks * a.ci_blocks;
@@ -114,10 +148,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
     // ---- tile-invariant per-lane DMA byte offsets: LDS slot i = piece*64 + lane ----
     // dY: slot -> (tile row r>>5, col r&31, swizzled channel slot) relative to the tile origin (always "valid": rows past
     // the image fall off the end of the per-image descriptor)
-    unsigned dy_off[C::NDY];
+    unsigned dy_off[Q::NDY];
 #pragma unroll
-    for (int j = 0; j < C::NDY; ++j) {
-        const int i = (C::NW * j + wave) * 64 + lane;
+    for (int j = 0; j < Q::NDY; ++j) {
+        const int i = (NW * j + wave) * 64 + lane;
         const int r = i / C::DY_SLOTS, sl = i % C::DY_SLOTS;
         const int s = sl ^ (((r >> 1) & 1) << 2);
         dy_off[j] = (unsigned)((((r >> 5) * a.W + (r & 31)) * a.lddy + s * 8) * 2);
@@ -125,10 +159,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
     // X halo: slot -> halo pixel (hy, hx) relative to the halo origin (oh0-1, ow0-1); the descriptor base is shifted back
     // by one row + one pixel so the offsets are non-negative.  x_flag marks the lanes that sit on a border the range check
     // cannot see (top row / left / right column): they are pushed out of range on the tiles that touch that border.
-    unsigned x_off[C::NX], x_flag[C::NX];
+    unsigned x_off[Q::NX], x_flag[Q::NX];
 #pragma unroll
-    for (int j = 0; j < C::NX; ++j) {
-        const int i = (C::NW * j + wave) * 64 + lane;
+    for (int j = 0; j < Q::NX; ++j) {
+        const int i = (NW * j + wave) * 64 + lane;
         const int p = i >> 3, sl = i & 7;
         const int hy = p / C::HALO_W, hx = p - hy * C::HALO_W;
         const int s = sl ^ (((hx >> 1) & 1) << 2);
@@ -157,12 +191,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
     };
     auto issue_piece = [&](int j, int buf) __attribute__((always_inline)) {
         const unsigned lds = smem_base + buf * C::BUF;
-        if (j < C::NDY) {
-            wu_dma16b(dy_off[j], rs_dy, so_dy, __builtin_amdgcn_readfirstlane(lds + (C::NW * j + wave) * 1024));
+        if (j < Q::NDY) {
+            wu_dma16b(dy_off[j], rs_dy, so_dy, __builtin_amdgcn_readfirstlane(lds + (NW * j + wave) * 1024));
         } else {
-            const int jj = j - C::NDY;
+            const int jj = j - Q::NDY;
             const unsigned vo = (x_flag[jj] & border_f) ? kWuOOB : x_off[jj];
-            wu_dma16b(vo, rs_x, so_x, __builtin_amdgcn_readfirstlane(lds + C::DY_BYTES + (C::NW * jj + wave) * 1024));
+            wu_dma16b(vo, rs_x, so_x, __builtin_amdgcn_readfirstlane(lds + C::DY_BYTES + (NW * jj + wave) * 1024));
         }
     };
 
@@ -187,7 +221,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    float bsum = 0.f;
+    float bs[8];             // dbias partials: this thread's 16-byte channel chunk (tid & 7) over its rows of every tile
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[e] = 0.f;
     const bool do_bias = (cib == 0) && (a.bslab != nullptr);
 
     // the tile loop is instantiated once per tap-half so each copy has a branch-free, fully unrolled body
@@ -199,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
         if (t_begin < t_end) {
             set_fetch_tile(t_begin);
 #pragma unroll
-            for (int j = 0; j < C::NDY + C::NX; ++j) issue_piece(j, 0);
+            for (int j = 0; j < Q::NDY + Q::NX; ++j) issue_piece(j, 0);
         }
         for (int tile = t_begin; tile < t_end; ++tile) {
             const int buf = (tile - t_begin) & 1;
@@ -211,19 +247,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
             if (more) set_fetch_tile(tile + 1);
             if (more && !a.dma_interleave) {
 #pragma unroll
-                for (int j = 0; j < C::NDY + C::NX; ++j) issue_piece(j, buf ^ 1);
+                for (int j = 0; j < Q::NDY + Q::NX; ++j) issue_piece(j, buf ^ 1);
             }
             const char* lds = smem + buf * C::BUF;
-            if (do_bias) {
-                const int co = tid & 63, part = tid >> 6;
-                for (int r = part; r < C::P; r += 8)
-                    bsum += bf16_to_f32(*(const bf16_t*)(lds + r * C::DY_ROW + ((co * 2) ^ (((r >> 1) & 1) << 6))));
+            if (do_bias) {       // 16-byte reads of the dY tile: 4 (8) per thread and tile instead of 32 (64) two-byte ones
+                const int c8 = tid & 7;
+#pragma unroll
+                for (int r = tid >> 3; r < C::P; r += NW * 8) {
+                    const uint4 v = *(const uint4*)(lds + r * C::DY_ROW + ((c8 ^ (((r >> 1) & 1) << 2)) << 4));
+                    float f[8];
+                    unpack16<bf16_t>(v, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bs[e] += f[e];
+                }
             }
-            compute_tile<HF>(lds, a_lane, b_lane, acc, [&](int kk) __attribute__((always_inline)) {
-                // 10 pieces, two per K-step pair over the first five
-                if (more && a.dma_interleave && kk < 5) {
-                    issue_piece(2 * kk, buf ^ 1);
-                    issue_piece(2 * kk + 1, buf ^ 1);
+            compute_tile<HF, Q::PARS>(lds, a_lane, b_lane, acc, [&](int g) __attribute__((always_inline)) {
+                // the wave's 10 (20) pieces, two per group over the first five (ten) groups
+                if (more && a.dma_interleave && 2 * g < Q::NDY + Q::NX) {
+                    issue_piece(2 * g, buf ^ 1);
+                    issue_piece(2 * g + 1, buf ^ 1);
                 }
             });
             WU_STAMP(t_comp);
@@ -240,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
     __syncthreads();   // all fragment reads done: LDS is free for the reductions below
 
     // ---- add the odd-K-step wave set into the even one through LDS ----
-    {
+    if (NW == 8) {
         float* red = (float*)smem + (size_t)(wave & 3) * 144 * 64;
         if (par == 1) {
 #pragma unroll
@@ -275,14 +317,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const W2Args a
             }
         }
     }
-    if (do_bias) {
+    if (do_bias) {           // fixed-order sum over the NW*8 row classes
         float* red = (float*)smem;
-        red[tid] = bsum;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bs[e];
         __syncthreads();
         if (tid < 64) {
             float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s += red[tid + 64 * k];
+            for (int j = 0; j < NW * 8; ++j) s += red[(j * 8 + (tid >> 3)) * 8 + (tid & 7)];
             a.bslab[(size_t)split * a.Cout + cob * 64 + tid] = s;
         }
     }
@@ -323,9 +365,12 @@ int wgrad_v2_launch(const void* x, int ldx, const void* dy, int lddy, float* sla
     const int grid = p.splits * p.co_blocks * p.ci_blocks;
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_v2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_v2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_wgrad_v2_kernel, dim3(grid), dim3(512), 2 * C::BUF, s, a);
+    // option 2: 1 = 8 waves, 2 = 4 waves (one per SIMD, no parity split)
+    if (g_wu_opt[WU_OPT_WGRAD_V2] == 2) hipLaunchKernelGGL(conv3x3_wgrad_v2_kernel<4>, dim3(grid), dim3(256), 2 * C::BUF, s, a);
+    else hipLaunchKernelGGL(conv3x3_wgrad_v2_kernel<8>, dim3(grid), dim3(512), 2 * C::BUF, s, a);
     return 0;
 }
