@@ -194,10 +194,17 @@ def test_conv3x3_c3(p, cfg):
     pp = "fp32" if out_nchw else p
     assert (y.float().cpu() - ref.detach()).abs().max().item() <= _tol(pp, ref.detach())
     y.backward(gy.to(_dev()) if out_nchw else _nhwc(gy, p))
-    # gating uses the stored (rounded) activations: compare with a loose-but-meaningful tolerance
+    # fp32: exact gating, tight max-abs.  bf16: the forward runs on the matrix cores with bf16-rounded image and weights, so
+    # pre-activations within ~1e-2 of zero can land on the other side of the ReLU / LeakyReLU kink than in the fp32
+    # reference -- the same gate-flip noise every bf16 layer has: relative-L2 bound instead of max-abs
     for name, got, want in (("dx", xg.grad, x.grad), ("dw", wg.grad, wt.grad), ("db", bg.grad, b.grad)):
-        err = (got.float().cpu() - want).abs().max().item()
-        assert err <= (2e-3 if pp == "bf16" else 2e-4) * max(1.0, float(want.abs().max())), f"{name}: {err}"
+        d = got.float().cpu() - want
+        if pp == "bf16":
+            rel = (d.norm() / want.norm()).item()
+            assert rel <= 4e-2, f"{name}: rel-L2 {rel}"
+        else:
+            err = d.abs().max().item()
+            assert err <= 2e-4 * max(1.0, float(want.abs().max())), f"{name}: {err}"
 
 
 @pytest.mark.parametrize("p", DTYPES)

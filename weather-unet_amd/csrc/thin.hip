@@ -62,6 +62,112 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(const float* __rest
     }
 }
 
+// bf16 production path of the 3->64 conv: the K = 27 (padded to 32) reduction on the matrix cores.
+//   D[co][pixel] = W[co][k] * patch[k][pixel]   (v_mfma_f32_32x32x16_bf16, two K-steps, two 32-channel halves)
+// A wave takes 32 consecutive output pixels per iteration: lane (pixel = lane & 31, K-half = lane >> 5) gathers its 2 x 8
+// patch values straight from the NCHW fp32 image (lanes = consecutive pixels: coalesced 128-B rows), rounds them to bf16
+// into the MFMA B operand -- no LDS, no barrier.  The 64 x 32 weight matrix lives in 16 registers per lane for the whole
+// kernel.  Accumulators are transposed (lane owns 4 consecutive channels of its pixel); the epilogue transposes through a
+// wave-private LDS patch (no barrier) so the stores cover whole pixel rows.  The VALU form above needs
+// 1728 fp32 FMAs per pixel (fp32 VALU peak = 1/16 of the bf16 matrix rate); this one is bound by the 268 MB it writes.
+template <int STRIDE, int ACT>
+__global__ __launch_bounds__(256) void conv3x3_c3_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, const float* __restrict__ inv_sigma,
+                                                                  bf16_t* __restrict__ y, int ldy, int N, int H, int W) {
+    __shared__ __attribute__((aligned(16))) char tile[4 * 32 * 144];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
+    const float sg = inv_sigma ? *inv_sigma : 1.f;
+    // weights as the MFMA A operand: row = co = 32 m + l31, k = 16 ks + 8 lh + j
+    uint4 wf[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * ks + 8 * lh + j;
+                f[j] = k < 27 ? w[(32 * m + l31) * 27 + k] * sg : 0.f;
+            }
+            wf[m][ks] = pack16<bf16_t>(f);
+        }
+    // this lane's 16 K slots: element offset relative to the centre input pixel, and (dh, dw) for the border test
+    const int HW = H * W;
+    int kch[16], kdh[16], kdw[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int k = 16 * (t >> 3) + 8 * lh + (t & 7);
+        const int ci = k < 27 ? k / 9 : 0, r = k - (k / 9) * 9, kh = r / 3, kw = r - kh * 3;
+        kch[t] = ci * HW;
+        kdh[t] = k < 27 ? kh - 1 : (1 << 20);          // an invalid slot never passes the row test
+        kdw[t] = kw - 1;
+    }
+    float4 bq[2][4];       // bias of channels 32 m + 8 g + 4 lh + (0..3)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[m][g] = bias ? *(const float4*)(bias + 32 * m + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
+    const int total = N * Ho * Wo;                 // < 2^31 (checked by the host): 32-bit index arithmetic
+    const int nblk = (total + 31) / 32;
+    for (int blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4) {
+        const int pix = blk * 32 + l31;
+        const bool ok = pix < total;
+        const int pc = ok ? pix : total - 1;
+        const int rowi = pc / Wo, ow = pc - rowi * Wo, n = rowi / Ho, oh = rowi - n * Ho;
+        const int ih0 = oh * STRIDE, iw0 = ow * STRIDE;
+        const float* xn = x + (size_t)n * 3 * HW;
+        // 16 UNCONDITIONAL loads from clamped coordinates, zeroed afterwards (a conditional load compiles to a branch with its
+        // own s_waitcnt: 16 serialized round trips per iteration)
+        float v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int ih = ih0 + kdh[t], iw = iw0 + kdw[t];
+            const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
+            v[t] = xn[kch[t] + ihc * W + iwc];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int ih = ih0 + kdh[t], iw = iw0 + kdw[t];
+            v[t] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? v[t] : 0.f;
+        }
+        const uint4 pf0 = pack16<bf16_t>(v), pf1 = pack16<bf16_t>(v + 8);
+        f32x16_t acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[m][0]), __builtin_bit_cast(bf16x8_t, pf0), acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[m][1]), __builtin_bit_cast(bf16x8_t, pf1), acc[m], 0, 0, 0);
+        }
+        // transposed accumulators -> [pixel][64 ch] rows in this wave's private LDS patch (144-B rows), then 16-byte stores
+        // that cover whole 128-byte pixel rows (8 lanes per pixel, 1 KiB contiguous per instruction when ldy == 64): the
+        // output stream is the kernel's roofline, and row-per-lane stores (32 lines touched per instruction) ran at 1.2 TB/s
+        char* tp = tile + wave * (32 * 144);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = bq[m][g];
+                const int r0 = 4 * g;
+                const uint32_t lo = pack_bf16x2(act_apply(acc[m][r0 + 0] + bv.x, ACT), act_apply(acc[m][r0 + 1] + bv.y, ACT));
+                const uint32_t hi = pack_bf16x2(act_apply(acc[m][r0 + 2] + bv.z, ACT), act_apply(acc[m][r0 + 3] + bv.w, ACT));
+                *(uint2*)(tp + l31 * 144 + (32 * m + 8 * g + 4 * lh) * 2) = make_uint2(lo, hi);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // same wave: LDS operations execute in order
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 8 * k + (lane >> 3), sl = lane & 7;
+            const int p2 = blk * 32 + r;
+            const uint4 v4 = *(const uint4*)(tp + r * 144 + sl * 16);
+            if (p2 < total) *(uint4*)(y + (size_t)p2 * ldy + sl * 8) = v4;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // NHWC-output form of the conv above (Cout = 64), production path.  One thread = one output pixel with its 27 inputs in
 // registers; the output channels are walked in the OUTER loop, so the weights w[co][0..26] are wave-uniform and come
 // through the scalar cache (s_load) straight into the FMAs: no LDS weight traffic (the LDS-broadcast form above spends
@@ -209,7 +315,9 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_mfma_kernel(const float*
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
-    float bsum = 0.f;
+    float bs8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs8[e] = 0.f;
     const int g16 = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, h = g16 >> 1;
 
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -232,23 +340,38 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_mfma_kernel(const float*
             const long long pix = base + tid;
             float pv[32];
 #pragma unroll
-            for (int k = 0; k < 32; ++k) pv[k] = 0.f;
-            if (pix < total) {
-                const int ow = (int)(pix % Wo), oh = (int)((pix / Wo) % Ho), n = (int)(pix / ((long long)Wo * Ho));
+            for (int k = 27; k < 32; ++k) pv[k] = 0.f;
+            {
+                // 27 UNCONDITIONAL loads from clamped coordinates, zeroed afterwards: a conditional load compiles to a branch
+                // with its own s_waitcnt (27 serialized round trips per tile)
+                const long long pc = pix < total ? pix : total - 1;
+                const long long rowi = pc / Wo;
+                const int ow = (int)(pc - rowi * Wo), n = (int)(rowi / Ho), oh = (int)(rowi - (long long)n * Ho);
                 const float* xn = x + (size_t)n * 3 * H * W;
 #pragma unroll
                 for (int k = 0; k < 27; ++k) {
                     const int ci = k / 9, t = k % 9, ih = oh * STRIDE + t / 3 - 1, iw = ow * STRIDE + t % 3 - 1;
-                    if (ih >= 0 && ih < H && iw >= 0 && iw < W) pv[k] = xn[((size_t)ci * H + ih) * W + iw];
+                    pv[k] = xn[((size_t)ci * H + min(max(ih, 0), H - 1)) * W + min(max(iw, 0), W - 1)];
+                }
+#pragma unroll
+                for (int k = 0; k < 27; ++k) {
+                    const int t = k % 9, ih = oh * STRIDE + t / 3 - 1, iw = ow * STRIDE + t % 3 - 1;
+                    pv[k] = (pix < total && ih >= 0 && ih < H && iw >= 0 && iw < W) ? pv[k] : 0.f;
                 }
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) *(uint4*)(pa_lds + tid * 64 + c * 16) = pack16<bf16_t>(pv + 8 * c);
         }
         __syncthreads();
-        if (dbias) {
-            const int co = tid & 63, part = tid >> 6;
-            for (int r = part; r < 256; r += 4) bsum += bf16_to_f32(*(const bf16_t*)(dy_lds + r * 128 + ((co * 2) ^ (((r >> 1) & 1) << 6))));
+        if (dbias) {       // 16-byte reads: 8 per thread and tile (was 64 two-byte ones)
+            const int c8 = tid & 7;
+#pragma unroll
+            for (int r = tid >> 3; r < 256; r += 32) {
+                float f[8];
+                unpack16<bf16_t>(*(const uint4*)(dy_lds + r * 128 + ((c8 ^ (((r >> 1) & 1) << 2)) << 4)), f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bs8[e] += f[e];
+            }
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -286,9 +409,14 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_mfma_kernel(const float*
     }
     if (dbias) {
         __syncthreads();
-        red[tid] = bsum;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bs8[e];
         __syncthreads();
-        if (tid < 64) atomicAdd(&dbias[tid], red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192]);
+        if (tid < 64) {
+            float sb = 0.f;
+            for (int j = 0; j < 32; ++j) sb += red[(j * 8 + (tid >> 3)) * 8 + (tid & 7)];
+            atomicAdd(&dbias[tid], sb);
+        }
     }
 }
 
@@ -370,26 +498,44 @@ __global__ __launch_bounds__(256) void conv3x3_c3_dgrad_nhwc_kernel(const T* __r
         int iw = 0, ih = 0, n = 0;
         if (pix < total) {
             iw = (int)(pix % W); ih = (int)((pix / W) % H); n = (int)(pix / ((long long)W * H));
+            // Candidate taps per dimension: all three at stride 1; at stride 2 only the taps of matching parity (kh = 1, or
+            // kh in {0, 2}).  Every candidate is loaded UNCONDITIONALLY from clamped coordinates and zeroed when it falls
+            // outside (a conditional load compiles to a branch with its own s_waitcnt: serialized round trips).
+            constexpr int NS = STRIDE == 1 ? 3 : 2;
+            uint4 gvs[NS * NS];
+            int taps[NS * NS];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
+            for (int a = 0; a < NS; ++a) {
+                const int ph = (ih + 1) & 1;
+                const int kh = STRIDE == 1 ? a : (ph ? (a == 0 ? 1 : 3) : 2 * a);
                 const int th = ih + 1 - kh;
-                if (th < 0 || (th % STRIDE) || th / STRIDE >= Ho) continue;
+                const bool okh = kh < 3 && th >= 0 && th / STRIDE < Ho;
+                const int ohc = min(max(th, 0) / STRIDE, Ho - 1);
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
+                for (int b = 0; b < NS; ++b) {
+                    const int pw = (iw + 1) & 1;
+                    const int kw = STRIDE == 1 ? b : (pw ? (b == 0 ? 1 : 3) : 2 * b);
                     const int tw = iw + 1 - kw;
-                    if (tw < 0 || (tw % STRIDE) || tw / STRIDE >= Wo) continue;
-                    const size_t op = ((size_t)n * Ho + th / STRIDE) * Wo + tw / STRIDE;
+                    const bool okw = kw < 3 && tw >= 0 && tw / STRIDE < Wo;
+                    const int owc = min(max(tw, 0) / STRIDE, Wo - 1);
+                    const size_t op = ((size_t)n * Ho + ohc) * Wo + owc;
                     uint4 gv = *(const uint4*)(dy + op * lddy + cl * E);
                     if (y) gv = gate16<T>(gv, *(const uint4*)(y + op * ldy + cl * E), act);
-                    float g[E];
-                    unpack16<T>(gv, g);
-                    const float* wt = wl + (kh * 3 + kw) * 3 * Cout + cl * E;
+                    const bool okk = okh && okw;
+                    gvs[a * NS + b] = okk ? gv : make_uint4(0u, 0u, 0u, 0u);
+                    taps[a * NS + b] = okk ? kh * 3 + kw : 0;
+                }
+            }
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        a0 += g[e] * wt[e];
-                        a1 += g[e] * wt[Cout + e];
-                        a2 += g[e] * wt[2 * Cout + e];
-                    }
+            for (int sidx = 0; sidx < NS * NS; ++sidx) {
+                float g[E];
+                unpack16<T>(gvs[sidx], g);
+                const float* wt = wl + taps[sidx] * 3 * Cout + cl * E;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    a0 += g[e] * wt[e];
+                    a1 += g[e] * wt[Cout + e];
+                    a2 += g[e] * wt[2 * Cout + e];
                 }
             }
         }
@@ -579,14 +725,21 @@ extern "C" int wu_conv3x3_c3_fwd(const float* x_nchw, const float* w_oihw, const
 #define C3_LANES_A(T, ST, A) hipLaunchKernelGGL((conv3x3_c3_fwd_rows_kernel<T, ST, A>), dim3(grid_l), dim3(256), 0, s, x_nchw, w_oihw, bias, inv_sigma, (T*)y, ldy, N, H, W)
 #define C3_LANES(T, ST) do { if (act == WU_ACT_RELU) C3_LANES_A(T, ST, WU_ACT_RELU); else if (act == WU_ACT_LEAKY) C3_LANES_A(T, ST, WU_ACT_LEAKY); else C3_LANES_A(T, ST, WU_ACT_NONE); } while (0)
     const int grid_l = grid_cap((long long)N * Ho * Wo, 256, 256 * 8);
-    // the LDS-broadcast one-thread-per-pixel kernel measured fastest (239 us at B=32 256x256); the scalar-weight /
-    // transposed-store variant (conv3x3_c3_fwd_rows_kernel, 326 us) is kept selectable for A/B work
+    // fp32 path: the LDS-broadcast one-thread-per-pixel kernel (239 us at B=32 256x256 in bf16 storage; the scalar-weight /
+    // transposed-store variant conv3x3_c3_fwd_rows_kernel measured 326 us and is kept selectable for A/B work)
+#define C3_MFMA_A(ST, A) hipLaunchKernelGGL((conv3x3_c3_fwd_mfma_kernel<ST, A>), dim3(grid_m), dim3(256), 0, s, x_nchw, w_oihw, bias, inv_sigma, (bf16_t*)y, ldy, N, H, W)
+#define C3_MFMA(ST) do { if (act == WU_ACT_RELU) C3_MFMA_A(ST, WU_ACT_RELU); else if (act == WU_ACT_LEAKY) C3_MFMA_A(ST, WU_ACT_LEAKY); else C3_MFMA_A(ST, WU_ACT_NONE); } while (0)
+    const int grid_m = grid_cap((long long)N * Ho * Wo, 128, 256 * 16);
+    // option 5: 0 = bf16 on the matrix cores (default), 1 = scalar-weight rows kernel, 2 = one-thread-per-pixel VALU kernel
     if (out_nchw) C3_LAUNCH(float, 3, 1, true);
-    else if (g_wu_opt[WU_OPT_C3_ROWS]) {
+    else if (dtype == WU_BF16 && g_wu_opt[WU_OPT_C3_ROWS] == 0 && (!bias || ((uintptr_t)bias % 16) == 0) && (long long)N * Ho * Wo < (1ll << 31) - 64) { if (stride == 1) C3_MFMA(1); else C3_MFMA(2); }
+    else if (g_wu_opt[WU_OPT_C3_ROWS] == 1) {
         if (dtype == WU_BF16) { if (stride == 1) C3_LANES(bf16_t, 1); else C3_LANES(bf16_t, 2); }
         else { if (stride == 1) C3_LANES(float, 1); else C3_LANES(float, 2); }
     } else if (dtype == WU_BF16) { if (stride == 1) C3_LAUNCH(bf16_t, 64, 1, false); else C3_LAUNCH(bf16_t, 64, 2, false); }
     else { if (stride == 1) C3_LAUNCH(float, 64, 1, false); else C3_LAUNCH(float, 64, 2, false); }
+#undef C3_MFMA
+#undef C3_MFMA_A
 #undef C3_LANES
 #undef C3_LANES_A
 #undef C3_LAUNCH_A
