@@ -170,14 +170,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
 
     // stride-2 tiles have a 4x larger halo: staged global -> LDS directly (no register prefetch)
     auto stage_direct = [&](int c0) __attribute__((always_inline)) {
-        for (int item = tid; item < a.halo_pix * 4; item += 256) {
-            const int p = item >> 2, slot = item & 3;
-            const int hy = p / a.halo_w, hx = p - hy * a.halo_w;
-            const int ih = ih0 + hy, iw = iw0 + hx;
-            uint4 v = zero4;
-            if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-                v = *(const uint4*)(xin + (size_t)(ih * a.W + iw) * a.ldx + slot * (16 / (int)sizeof(T)) + c0);
-            *(uint4*)(halo_lds + swz_off(p, slot)) = v;
+        // batches of 4 UNCONDITIONAL loads from clamped coordinates, zeroed afterwards (a conditional load in a rolled loop is
+        // one full memory round trip per item)
+        const int nitems = a.halo_pix * 4;
+        for (int item0 = tid; item0 < nitems; item0 += 1024) {
+            uint4 v[4];
+            bool okv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int item = min(item0 + 256 * u, nitems - 1);
+                const int p = item >> 2, slot = item & 3;
+                const int hy = p / a.halo_w, hx = p - hy * a.halo_w;
+                const int ih = ih0 + hy, iw = iw0 + hx;
+                okv[u] = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                v[u] = *(const uint4*)(xin + (size_t)(min(max(ih, 0), a.H - 1) * a.W + min(max(iw, 0), a.W - 1)) * a.ldx + slot * (16 / (int)sizeof(T)) + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int item = item0 + 256 * u;
+                if (item < nitems) *(uint4*)(halo_lds + swz_off(item >> 2, item & 3)) = okv[u] ? v[u] : zero4;
+            }
         }
 #define WU_COPYW(t) *(uint4*)(w_lds + (t) * (kBN * kChunkBytes) + wdst) = *(const uint4*)(wsrc + (t) * wtap_stride + c0);
         WU_REP9(WU_COPYW)

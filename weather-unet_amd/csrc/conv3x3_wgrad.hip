@@ -77,28 +77,59 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradArgs a
         {
             const T* dyb = (const T*)a.dy + (size_t)n * a.Ho * a.Wo * a.lddy + cob * 64;
             const T* yb = a.y ? (const T*)a.y + (size_t)n * a.Ho * a.Wo * a.ldy + cob * 64 : nullptr;
-            for (int item = tid; item < P * SLOTS; item += 256) {
-                const int r = item / SLOTS, s = item % SLOTS;
-                const int rx = r & (TW - 1), oh = oh0 + (r >> a.tw_log2), ow = ow0 + rx;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (oh < a.Ho && ow < a.Wo) {
-                    const size_t o = (size_t)(oh * a.Wo + ow);
-                    v = *(const uint4*)(dyb + o * a.lddy + s * E);
-                    if (yb) v = gate16<T>(v, *(const uint4*)(yb + o * a.ldy + s * E), a.act);
+            // loads in batches of 4, UNCONDITIONAL from clamped coordinates and zeroed afterwards: a conditional load in a rolled
+            // loop is one full memory round trip per item
+            static_assert((P * SLOTS) % 1024 == 0 || P * SLOTS < 1024, "dY staging batch");
+            for (int item0 = tid; item0 < P * SLOTS; item0 += 1024) {
+                uint4 v[4], yv[4];
+                bool okv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int item = min(item0 + 256 * u, P * SLOTS - 1);
+                    const int r = item / SLOTS, s = item % SLOTS;
+                    const int rx = r & (TW - 1), oh = oh0 + (r >> a.tw_log2), ow = ow0 + rx;
+                    okv[u] = oh < a.Ho && ow < a.Wo;
+                    const size_t o = (size_t)(min(oh, a.Ho - 1) * a.Wo + min(ow, a.Wo - 1));
+                    v[u] = *(const uint4*)(dyb + o * a.lddy + s * E);
+                    if (yb) yv[u] = *(const uint4*)(yb + o * a.ldy + s * E);
                 }
-                *(uint4*)(dy_lds + lds_off<T>(r, r, s * 16)) = v;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int item = item0 + 256 * u;
+                    if (item < P * SLOTS) {
+                        const int r = item / SLOTS, s = item % SLOTS;
+                        uint4 w = v[u];
+                        if (yb) w = gate16<T>(w, yv[u], a.act);
+                        *(uint4*)(dy_lds + lds_off<T>(r, r, s * 16)) = okv[u] ? w : make_uint4(0, 0, 0, 0);
+                    }
+                }
             }
         }
         // ---- stage X halo tile ----
         {
             const T* xb = (const T*)a.x + (size_t)n * a.H * a.W * a.ldx + cib * 64;
-            for (int item = tid; item < a.halo_pix * SLOTS; item += 256) {
-                const int p = item / SLOTS, s = item % SLOTS;
-                const int hy = p / a.halo_w, hx = p - hy * a.halo_w;
-                const int ih = ih0 + hy, iw = iw0 + hx;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = *(const uint4*)(xb + (size_t)(ih * a.W + iw) * a.ldx + s * E);
-                *(uint4*)(x_lds + lds_off<T>(p, hx, s * 16)) = v;
+            const int nitems = a.halo_pix * SLOTS;
+            for (int item0 = tid; item0 < nitems; item0 += 1024) {
+                uint4 v[4];
+                bool okv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int item = min(item0 + 256 * u, nitems - 1);
+                    const int p = item / SLOTS, s = item % SLOTS;
+                    const int hy = p / a.halo_w, hx = p - hy * a.halo_w;
+                    const int ih = ih0 + hy, iw = iw0 + hx;
+                    okv[u] = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                    v[u] = *(const uint4*)(xb + (size_t)(min(max(ih, 0), a.H - 1) * a.W + min(max(iw, 0), a.W - 1)) * a.ldx + s * E);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int item = item0 + 256 * u;
+                    if (item < nitems) {
+                        const int p = item / SLOTS, s = item % SLOTS;
+                        const int hy = p / a.halo_w, hx = p - hy * a.halo_w;
+                        *(uint4*)(x_lds + lds_off<T>(p, hx, s * 16)) = okv[u] ? v[u] : make_uint4(0, 0, 0, 0);
+                    }
+                }
             }
         }
         __syncthreads();
