@@ -5,6 +5,7 @@ from wu import _lib, kernels as K
 from wu.layout import empty_nhwc
 dev = torch.device('cuda:0'); B = 32
 NWAVES = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+if len(sys.argv) > 2: _lib.call('wu_set_option', 6, int(sys.argv[2]))
 _lib.call('wu_set_option', 0, 3 if NWAVES == 8 else 2)
 dbg = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
 for name, ci, co, s in [('d1.2', 64, 64, 256), ('d2.2', 128, 128, 128), ('d4.2', 512, 512, 32), ('u1.0', 192, 64, 256)]:

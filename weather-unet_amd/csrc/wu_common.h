@@ -54,7 +54,11 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    // ONE v_cvt_pk_bf16_f32 for the pair (two scalar casts + or compile to two single-operand cvt_pk and a v_perm)
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    const bf16x2v r = __builtin_convertvector(f32x2v{lo, hi}, bf16x2v);
+    return __builtin_bit_cast(uint32_t, r);
 }
 
 template <typename T> struct ElemTraits;
