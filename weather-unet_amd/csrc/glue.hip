@@ -292,7 +292,17 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_gather_kernel(
     constexpr int E = ElemTraits<T>::kPer16B;
     constexpr int LP = 64 / E, PP = 256 / LP;
     __shared__ float red[PP][64][2];
+    // keep-byte -> four dwords of 16-bit lane masks (bf16 only): the dropout mask is ANDed onto the PACKED gradient chunk
+    // (1 LDS read + 4 v_and per tap) instead of a bit test + compare + select per element and tap
+    __shared__ uint4 lut[E == 8 ? 256 : 1];
     const int tid = threadIdx.x;
+    if (E == 8 && thr < 0x10000u && mbits) {
+        uint32_t m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = ((tid >> (2 * k)) & 1 ? 0x0000ffffu : 0u) | ((tid >> (2 * k + 1)) & 1 ? 0xffff0000u : 0u);
+        lut[tid] = make_uint4(m[0], m[1], m[2], m[3]);
+        __syncthreads();
+    }
     const int cg = blockIdx.x, n = blockIdx.z;
     const int cl = tid % LP, pl = tid / LP;
     const int c0 = cg * 64 + cl * E;
@@ -342,20 +352,26 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_gather_kernel(
                 float d[E];
                 unpack16<T>(dv[ka * 4 + kb], d);
                 if (thr < 0x10000u) {
-                    if (mbits) {
+                    if (mbits && E == 8) {
+                        const uint4 mk = lut[bv[ka * 4 + kb] & 255u];
+                        const uint4 dm = make_uint4(dv[ka * 4 + kb].x & mk.x, dv[ka * 4 + kb].y & mk.y, dv[ka * 4 + kb].z & mk.z, dv[ka * 4 + kb].w & mk.w);
+                        unpack16<T>(dm, d);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) g[e] = fmaf(wgt, d[e], g[e]);
+                    } else if (mbits) {
                         const uint32_t bits = bv[ka * 4 + kb];
 #pragma unroll
-                        for (int e = 0; e < E; ++e) g[e] += ((bits >> e) & 1u) ? wgt * d[e] : 0.f;
+                        for (int e = 0; e < E; ++e) g[e] = ((bits >> e) & 1u) ? fmaf(wgt, d[e], g[e]) : g[e];
                     } else {
                         bool keep[E];
                         const size_t opix = (size_t)(n * H2 + iys[ka]) * W2 + jxs[kb];
                         keep_bits<E>(seed, (uint64_t)opix * C + c0, thr, keep);
 #pragma unroll
-                        for (int e = 0; e < E; ++e) g[e] += keep[e] ? wgt * d[e] : 0.f;
+                        for (int e = 0; e < E; ++e) g[e] = keep[e] ? fmaf(wgt, d[e], g[e]) : g[e];
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) g[e] += wgt * d[e];
+                    for (int e = 0; e < E; ++e) g[e] = fmaf(wgt, d[e], g[e]);
                 }
             }
         if (thr < 0x10000u) {
