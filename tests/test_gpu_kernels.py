@@ -48,6 +48,8 @@ CONV_SHAPES = [
     (1, 128, 128, 4, 4, 1),       # 4x4 bottleneck of a 32x32 input
     (3, 64, 64, 33, 35, 1),       # odd sizes
     (2, 192, 128, 40, 72, 1),     # several tiles per split in the LDS-DMA wgrad, ragged in both directions
+    (1, 256, 128, 20, 40, 1),     # Cin >= 256: the one-wave-per-SIMD (NW = 4) conv shape, 8 chunks per tile, ragged
+    (2, 384, 64, 16, 64, 1),      # NW = 4, 12 chunks, W % 32 == 0 (LDS-DMA wgrad eligible), 6 ci-blocks
     (2, 64, 128, 16, 32, 2),      # discriminator stride-2
     (1, 128, 64, 10, 12, 2),
 ]
