@@ -247,25 +247,32 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                 for (int ni = 0; ni < 2; ++ni)
                     bf[ni] = *(const uint4*)(lds + b_lane[ks] + (tap * 64 + 32 * ni) * 64);
             };
-            uint4 af[2][Q::RPW], bf[2][2];
             if constexpr (NW == 8) {
+                // fragments TWO steps ahead (ring of three register sets): whichever wave of a SIMD loses the arbitration runs
+                // the tail of the chunk alone, and a lone wave's 4 MFMAs per step (128 cycles) do not cover an LDS round trip
+                uint4 af[3][Q::RPW], bf[3][2];
                 load_step(0, af[0], bf[0]);
+                load_step(1, af[1], bf[1]);
 #pragma unroll
                 for (int step = 0; step < 18; ++step) {
-                    const int cur = step & 1;
-                    if (step + 1 < 18) load_step(step + 1, af[cur ^ 1], bf[cur ^ 1]);
+                    if (step + 2 < 18) load_step(step + 2, af[(step + 2) % 3], bf[(step + 2) % 3]);
                     // issue the next chunk's 10 DMA pieces at the START of this chunk (2 per step): they get ~3/4 of the chunk to
                     // land (LDS-DMA latency ~1.2 us)
                     if (more && 2 * step < Q::NP) {
                         issue_piece(2 * step, c1, nxt);
                         if (2 * step + 1 < Q::NP) issue_piece(2 * step + 1, c1, nxt);
                     }
+                    // pin the order: left alone, the scheduler sinks the fragment reads of the DMA-free steps (6..17) to just
+                    // before their first use and waits lgkmcnt(0) in front of every MFMA
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int mi = 0; mi < Q::RPW; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) mma(acc[mi][ni], bf[cur][ni], af[cur][mi]);   // D^T = W * X^T
+                        for (int ni = 0; ni < 2; ++ni) mma(acc[mi][ni], bf[step % 3][ni], af[step % 3][mi]);   // D^T = W * X^T
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
+                uint4 af[2][Q::RPW], bf[2][2];
                 // ONE wave per SIMD: nothing else fills the matrix pipe while this wave issues loads, so the stream is pinned
                 // instruction by instruction: after MFMA m of step s comes fragment read m of step s+1 (6 reads over the
                 // first 6 of 8 MFMAs), the DMA pieces ride behind the last MFMA; the whole chunk is one basic block.
