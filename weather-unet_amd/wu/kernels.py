@@ -16,8 +16,9 @@ _WS = {}
 
 
 def workspace(nbytes, device):
-    """One growable caller-owned byte buffer per device (the C ABI never allocates)."""
-    key = (device.type, device.index)
+    """One growable caller-owned byte buffer per device AND stream (the C ABI never allocates; kernels enqueued on different
+    streams must not share or regrow each other's scratch)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)

@@ -18,6 +18,18 @@ from . import kernels as K
 from .layout import empty_nhwc, precision_code, torch_dtype
 
 RELU = K.ACT_RELU
+# Weight-gradient kernels run on a second HIP stream: nothing in the backward chain consumes dW, so each one overlaps the
+# data-gradient kernel that follows it and the tails / ramps of the persistent one-workgroup-per-CU launches fill each other.
+SIDE_STREAM_WGRAD = True
+_SIDE = {}
+
+
+def _side_stream(dev):
+    s = _SIDE.get(dev)
+    if s is None:
+        s = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return s
+
 BLOCKS = ("dconv_down1", "dconv_down2", "dconv_down3", "dconv_down4", "dconv_up3", "dconv_up2", "dconv_up1")
 
 
@@ -121,11 +133,22 @@ class UNetFn(Function):
                 sink.grad_written(SP[iw])
                 sink.grad_written(SP[iw + 1])
 
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if SIDE_STREAM_WGRAD else None
+        keep = []          # operands of side-stream kernels stay referenced until the streams are joined
+
         def wgrad(name, j, xin, gy):
             iw = 4 * BLOCKS.index(name) + j
             dw, db, acc = grad_bufs(iw)
-            K.conv3x3_wgrad(xin, gy, dw, db, accumulate=acc)
-            done((name, j), iw, dw, db)
+            if side is None:
+                K.conv3x3_wgrad(xin, gy, dw, db, accumulate=acc)
+                done((name, j), iw, dw, db)
+                return
+            side.wait_stream(main)                    # xin / gy producers are enqueued on the main stream
+            with torch.cuda.stream(side):
+                K.conv3x3_wgrad(xin, gy, dw, db, accumulate=acc)
+                done((name, j), iw, dw, db)           # a sink's all-reduce must order after THIS stream
+            keep.append((xin, gy, dw, db))
 
         def block_bwd(name, xin, mid, g_out_gated, need_dx=True):
             """r_double_conv backward given the PRE-GATED gradient of its output; returns dL/d(xin) (ungated)."""
@@ -176,6 +199,9 @@ class UNetFn(Function):
             dx = torch.empty_like(x)
             K.conv3x3_c3_dgrad(g_a1, w_first.contiguous(), dx, 1, code)
 
+        if side is not None:
+            main.wait_stream(side)
+            keep.clear()
         flat = []
         for name in BLOCKS:
             for j in (0, 2):
