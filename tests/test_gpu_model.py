@@ -472,3 +472,29 @@ def test_fused_backward_gradient_sink():
     for k in ("dconv_up1.2.weight", "dconv_down4.0.bias", "adain2.fc_std.weight" if "adain2.fc_std.weight" in ref else "dconv_up3.0.weight"):
         assert torch.allclose(dict(net.named_parameters())[k].grad, 2 * ref[k], rtol=1e-5, atol=1e-8), k
     net.grad_sink = None
+
+
+def test_side_stream_wgrad_is_bitwise_neutral():
+    """The weight-gradient kernels run on a second HIP stream in the fused backward (wu/unet_graph.py): same kernels, same
+    operands, different queue -- every gradient must be bit-identical to the single-stream schedule."""
+    from wu import unet_graph as UG
+    nc = 5
+    net = _make_g(nc, 6, "bf16").train()
+    net.dropout_seed = 3
+    x, c = (t.to(DEV) for t in O.make_inputs(2, 64, nc, 6, True))
+    grads = {}
+    try:
+        for flag in (True, False):
+            UG.SIDE_STREAM_WGRAD = flag
+            for p in net.parameters():
+                p.grad = None
+            torch.mean(torch.abs(net(x, c) - x)).backward()
+            torch.cuda.synchronize()
+            grads[flag] = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    finally:
+        UG.SIDE_STREAM_WGRAD = True
+    for k in grads[True]:
+        if k.startswith(("dconv_down1.0", "conv_last")):       # fp32 atomics (see test_full_size_properties)
+            assert torch.allclose(grads[True][k], grads[False][k], rtol=1e-4, atol=1e-7), k
+        else:
+            assert torch.equal(grads[True][k], grads[False][k]), k
