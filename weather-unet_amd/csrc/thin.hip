@@ -497,7 +497,10 @@ __global__ __launch_bounds__(256) void conv3x3_c3_dgrad_nhwc_kernel(const T* __r
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
         int iw = 0, ih = 0, n = 0;
         if (pix < total) {
-            iw = (int)(pix % W); ih = (int)((pix / W) % H); n = (int)(pix / ((long long)W * H));
+            {   // 32-bit index arithmetic (64-bit divisions cost several hundred instructions per pixel)
+                const unsigned p32 = (unsigned)pix, rowi = p32 / (unsigned)W;
+                iw = (int)(p32 - rowi * (unsigned)W); n = (int)(rowi / (unsigned)H); ih = (int)(rowi - (unsigned)n * (unsigned)H);
+            }
             // Candidate taps per dimension: all three at stride 1; at stride 2 only the taps of matching parity (kh = 1, or
             // kh in {0, 2}).  Every candidate is loaded UNCONDITIONALLY from clamped coordinates and zeroed when it falls
             // outside (a conditional load compiles to a branch with its own s_waitcnt: serialized round trips).
@@ -794,7 +797,7 @@ extern "C" int wu_conv3x3_c3_dgrad(const void* dy, int lddy, int dy_nchw, const 
     const size_t lds = (size_t)27 * Cout * sizeof(float);
     const int esz_ = dtype == WU_BF16 ? 2 : 4;
     const int lp_ = dy_nchw ? 0 : Cout / (16 / esz_);
-    if (!dy_nchw && Cout % (16 / esz_) == 0 && lp_ >= 1 && lp_ <= 64 && (lp_ & (lp_ - 1)) == 0 && ((uintptr_t)dy % 16) == 0 && (lddy * esz_) % 16 == 0 &&
+    if (!dy_nchw && (long long)N * H * W < (1ll << 32) && Cout % (16 / esz_) == 0 && lp_ >= 1 && lp_ <= 64 && (lp_ & (lp_ - 1)) == 0 && ((uintptr_t)dy % 16) == 0 && (lddy * esz_) % 16 == 0 &&
         (!y || (((uintptr_t)y % 16) == 0 && (ldy_ * esz_) % 16 == 0))) {
         const int g = grid_cap((long long)N * H * W, 256 / lp_, 256 * 16);
 #define C3DN(T, ST) hipLaunchKernelGGL((conv3x3_c3_dgrad_nhwc_kernel<T, ST>), dim3(g), dim3(256), lds, s, (const T*)dy, lddy, (const T*)y, ldy_, act, w_oihw, inv_sigma, dx_nchw, N, H, W, Cout, accumulate)
