@@ -150,6 +150,16 @@ int wu_maxpool2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int 
 int wu_maxpool2_bwd(const void* x, int ldx, const void* dy, int lddy, const void* dskip, int lddskip,
                     void* dx, int lddx, int N, int H, int W, int C, int gate_act, int dtype, void* stream);
 
+/* AdaIN style statistics (utils.py:41-48): y_ = l1(y).view(N, C, 4) with l1 = Linear(nc, 4C) (w: [4C][nc] fp32, b: [4C] or NULL);
+ * y_mean[n][c] = mean_k y_[n][c][k], y_std[n][c] = sqrt(unbiased var_k + eps).  `y4` (may be NULL; N*C*4 floats, 16-B aligned)
+ * receives y_ for the backward pass.  One launch instead of ~8 stock kernels; nc <= 32. */
+int wu_adain_style_fwd(const float* y, const float* w, const float* b, float eps, float* y_std, float* y_mean, float* y4,
+                       int N, int C, int nc, void* stream);
+/* Gradients of the above wrt l1.weight (dw [4C][nc]) and l1.bias (db [4C], may be NULL) from d_std, d_mean [N][C]
+ * (autograd of utils.py:41-48); fixed summation order over n.  accumulate != 0 adds into dw / db. */
+int wu_adain_style_bwd(const float* d_std, const float* d_mean, const float* y, const float* y4, const float* y_std,
+                       const float* y_mean, float* dw, float* db, int N, int C, int nc, int accumulate, void* stream);
+
 /* AdaIN instance statistics (utils.py:34-39,47): per (n,c) over H*W: stats[n][c] = {mean, rstd}
  * with rstd = 1/sqrt(unbiased_var + eps).  `scratch` holds N*C*2*WU_MAX_SPLITS floats (per-split partial
  * sums, folded in fixed order: results are bitwise reproducible). */

@@ -382,3 +382,24 @@ def test_rejects_bad_arguments():
         WF.conv3x3(x, torch.zeros(64, 40, 3, 3, device=_dev()), None, WF.PackedConv(), 1, 0)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         WF.maxpool2(torch.zeros(1, 64, 8, 8))
+
+
+def test_adain_style_fused():
+    """utils.py:41-48: l1(y).view(N, C, 4) -> (sqrt(unbiased var + eps), mean) and its gradients into l1, one kernel each,
+    against stock autograd (fp32)."""
+    from wu import functional as WF
+    n, c, nc, eps = 6, 40, 5, 1e-5
+    y = _rand((n, nc), 71)
+    w = _rand((4 * c, nc), 72).requires_grad_(True)
+    b = _rand((4 * c,), 73).requires_grad_(True)
+    y_ = F.linear(y, w, b).view(n, c, 4)
+    ref_std, ref_mean = (y_.var(dim=-1) + eps).sqrt(), y_.mean(dim=-1)
+    gs, gm = _rand((n, c), 74), _rand((n, c), 75)
+    (ref_std * gs + ref_mean * gm).sum().backward()
+    wg = w.detach().to(_dev()).requires_grad_(True)
+    bg = b.detach().to(_dev()).requires_grad_(True)
+    std, mean = WF.adain_style(y.to(_dev()), wg, bg, eps)
+    assert (std.cpu() - ref_std.detach()).abs().max().item() <= 1e-5 and (mean.cpu() - ref_mean.detach()).abs().max().item() <= 1e-5
+    (std * gs.to(_dev()) + mean * gm.to(_dev())).sum().backward()
+    assert (wg.grad.cpu() - w.grad).abs().max().item() <= 2e-5 * max(1.0, float(w.grad.abs().max()))
+    assert (bg.grad.cpu() - b.grad).abs().max().item() <= 2e-5 * max(1.0, float(b.grad.abs().max()))

@@ -363,3 +363,44 @@ class SpectralNormFn(Function):
 
 def spectral_normalize(weight_orig, u, v, do_power_iteration, eps=1e-12):
     return SpectralNormFn.apply(weight_orig, u, v, do_power_iteration, eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# AdaIN style statistics: l1(y).view(N, C, 4) -> (std, mean)                    utils.py:41-48
+# ----------------------------------------------------------------------------------------------
+class AdaINStyleFn(Function):
+    """(y_std, y_mean) from the conditioning vector in ONE kernel (and one for the backward into l1.weight / l1.bias) instead of
+    the ~15 launch-sized stock kernels per decoder level and direction.  The conditioning input itself gets no gradient (labels)."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias, eps):
+        n, nc = y.shape
+        c = weight.shape[0] // 4
+        y = y.contiguous()
+        w = weight.detach().contiguous()
+        y_std = torch.empty((n, c), dtype=torch.float32, device=y.device)
+        y_mean = torch.empty_like(y_std)
+        y4 = torch.empty((n, c, 4), dtype=torch.float32, device=y.device)
+        _lib.call("wu_adain_style_fwd", y.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, float(eps),
+                  y_std.data_ptr(), y_mean.data_ptr(), y4.data_ptr(), n, c, nc, stream_ptr())
+        ctx.save_for_backward(y, y4, y_std, y_mean)
+        ctx.meta = (tuple(weight.shape), bias is not None)
+        return y_std, y_mean
+
+    @staticmethod
+    def backward(ctx, d_std, d_mean):
+        y, y4, y_std, y_mean = ctx.saved_tensors
+        wshape, has_bias = ctx.meta
+        n, nc = y.shape
+        c = wshape[0] // 4
+        d_std = (d_std if d_std is not None else torch.zeros_like(y_std)).float().contiguous()
+        d_mean = (d_mean if d_mean is not None else torch.zeros_like(y_mean)).float().contiguous()
+        dw = torch.empty(wshape, dtype=torch.float32, device=y.device)
+        db = torch.empty((wshape[0],), dtype=torch.float32, device=y.device) if has_bias else None
+        _lib.call("wu_adain_style_bwd", d_std.data_ptr(), d_mean.data_ptr(), y.data_ptr(), y4.data_ptr(), y_std.data_ptr(), y_mean.data_ptr(),
+                  dw.data_ptr(), db.data_ptr() if db is not None else None, n, c, nc, 0, stream_ptr())
+        return None, dw, db, None
+
+
+def adain_style(y, weight, bias, eps):
+    return AdaINStyleFn.apply(y, weight, bias, eps)
