@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void adain_style_bwd_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < kMaxNc; ++j) acc[j] = 0.f;
     float bs = 0.f;
-    for (int n = 0; n < N; ++n) {
+#pragma unroll 8
+    for (int n = 0; n < N; ++n) {       // loads of 8 samples in flight (the accumulation order stays n = 0, 1, 2, ...)
         const int i = n * C + c;
         const float g = d_mean[i] * 0.25f + d_std[i] * (y4[(size_t)i * 4 + k] - y_mean[i]) / (3.f * y_std[i]);
         bs += g;
