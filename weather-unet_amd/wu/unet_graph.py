@@ -125,17 +125,26 @@ class UNetFn(Function):
                 return torch.empty(shapes[iw], **f32), torch.empty(shapes[iw + 1], **f32), False
             return SP[iw].grad, SP[iw + 1].grad, True
 
-        def done(key, iw, dw, db):
-            if sink is None:
-                grads[key] = (dw, db)
-            else:
-                grads[key] = (None, None)
-                sink.grad_written(SP[iw])
-                sink.grad_written(SP[iw + 1])
-
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if SIDE_STREAM_WGRAD else None
         keep = []          # operands of side-stream kernels stay referenced until the streams are joined
+
+        def done(key, iw, dw, db):
+            if sink is None:
+                grads[key] = (dw, db)
+                return
+            grads[key] = (None, None)
+            # A bucket's all-reduce is ordered after the stream that is current when its LAST gradient is announced, and a
+            # bucket mixes gradients produced on both streams: always announce on the side stream, after it has caught up with
+            # the main one (side >= main >= every producer enqueued so far)
+            if side is not None and torch.cuda.current_stream(dev) != side:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    sink.grad_written(SP[iw])
+                    sink.grad_written(SP[iw + 1])
+            else:
+                sink.grad_written(SP[iw])
+                sink.grad_written(SP[iw + 1])
 
         def wgrad(name, j, xin, gy):
             iw = 4 * BLOCKS.index(name) + j
