@@ -65,6 +65,7 @@ class GradBucketReducer:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
         backend = dist.get_backend(group) if dist.is_initialized() else None
         self._avg_op = backend == "nccl"       # RCCL has a native AVG; gloo needs SUM + scale
+        self._written = set()                  # parameters whose gradient was written since zero_grad()
         self.launch_log = []                   # bucket indices in launch order (tests / tracing)
         self.enabled = True                    # False: gradients deposited by a backward are ignored (not reduced)
         if broadcast and self.world > 1:
@@ -93,6 +94,12 @@ class GradBucketReducer:
             b["work"] = None
             b["launched"] = False
         self.launch_log.clear()
+        self._written.clear()
+
+    def fresh(self, p):
+        """True until a gradient of `p` has been written since zero_grad(): the first writer may OVERWRITE the (zeroed) bucket
+        view instead of read-modify-writing it; later backward passes without zero_grad() must accumulate."""
+        return p not in self._written
 
     def _launch(self, bi):
         b = self.buckets[bi]
@@ -107,6 +114,7 @@ class GradBucketReducer:
             b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
 
     def _on_grad_ready(self, p):
+        self._written.add(p)               # any arrival (autograd hook or direct write): later writers must accumulate
         if not self.enabled:
             return
         bi = self._bucket_of[p]

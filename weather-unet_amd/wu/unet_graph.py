@@ -123,7 +123,8 @@ class UNetFn(Function):
             """(dw, db, accumulate) for parameters iw, iw+1: fresh tensors handed to autograd, or the bucket views."""
             if sink is None:
                 return torch.empty(shapes[iw], **f32), torch.empty(shapes[iw + 1], **f32), False
-            return SP[iw].grad, SP[iw + 1].grad, True
+            # first write after zero_grad() overwrites the zeroed view (no read-modify-write); later ones accumulate
+            return SP[iw].grad, SP[iw + 1].grad, not (sink.fresh(SP[iw]) and sink.fresh(SP[iw + 1]))
 
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if SIDE_STREAM_WGRAD else None
