@@ -20,10 +20,12 @@ for name, ci, co, s in [('d1.2', 64, 64, 256), ('d2.2', 128, 128, 128), ('d4.2',
     e0.record(); K.conv3x3(x, wf, bias, y, 1, 1); e1.record(); torch.cuda.synchronize()
     _lib.call('wu_set_debug_buffer', None)
     d = dbg.view(256, 8, 8).double().cpu()[:, :NWAVES]
-    tiles, chunks = d[0, 0, 6].item(), d[0, 0, 7].item()
+    raw7 = dbg.view(256, 8, 8)[:, :NWAVES, 7].cpu()
+    tiles, chunks = d[0, 0, 6].item(), float(int(raw7[0, 0].item()) & 255)
+    first = (raw7 >> 8).double().mean().item()
     clk = (d[:, 0, 2] / d[:, 0, 3]).median().item() * 0.1
     ph = d[:, :, :6].mean(dim=(0, 1)); ph[2] = 0; ph[3] = 0
     tot = ph.sum().item()
     names = ['dma wait', 'compute', '-', '-', 'chunk-top barrier', 'epilogue']
     print(f"{name}: kernel {e0.elapsed_time(e1)*1e3:.0f} us, tiles/WG {tiles:.0f}, chunks {chunks:.0f}; cycles per tile: " +
-          ", ".join(f"{n} {v/tiles:.0f}" for n, v in zip(names, ph.tolist())) + f"; in-kernel clock {clk:.2f} GHz; total/tile {tot/tiles:.0f} cyc; compute/chunk {ph[1].item()/tiles/chunks:.0f}")
+          ", ".join(f"{n} {v/tiles:.0f}" for n, v in zip(names, ph.tolist())) + f"; in-kernel clock {clk:.2f} GHz; first chunk {first/tiles:.0f}, later chunks avg {(ph[1].item() - first)/tiles/max(chunks-1,1):.0f}; total/tile {tot/tiles:.0f} cyc; compute/chunk {ph[1].item()/tiles/chunks:.0f}")

@@ -43,7 +43,7 @@ struct V2Args {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; const bf16_t* egate;
     int ldx, ldy, ldegate, egate_act;
     int N, H, W, Cin, Cout, act;
-    int tiles_x, tiles_y, cout_tiles, ntiles, ct_slowest, prio_mode, strided;
+    int tiles_x, tiles_y, cout_tiles, ntiles, prio_mode, strided;
     unsigned long long* dbg;     // diagnostic: per-workgroup phase cycle sums (NULL in production)
 };
 
@@ -84,6 +84,27 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
     const int t_begin = a.strided ? wg : (int)((long long)a.ntiles * wg / gridDim.x);
     const int t_end = a.strided ? a.ntiles : (int)((long long)a.ntiles * (wg + 1) / gridDim.x);
     if (t_begin >= t_end) return;
+    // Tile coordinates (cout tile fastest, then tx, ty, n) are carried INCREMENTALLY: one decode by division per workgroup,
+    // then the constant stride t_step is added digit by digit.  (Four div/mod pairs per tile were ~200 VALU instructions that
+    // a one-wave-per-SIMD workgroup cannot hide: +2400 cycles on the last chunk of every tile.)
+    struct Tc { int ct, tx, ty, n; };
+    auto decode = [&](int tile) __attribute__((always_inline)) {
+        Tc t;
+        int tt = tile;
+        t.ct = tt % a.cout_tiles; tt /= a.cout_tiles;
+        t.tx = tt % a.tiles_x; tt /= a.tiles_x;
+        t.ty = tt % a.tiles_y;
+        t.n = tt / a.tiles_y;
+        return t;
+    };
+    const Tc dstep = decode(t_step);              // t_step in the same mixed radix
+    auto advance = [&](Tc t) __attribute__((always_inline)) {
+        t.ct += dstep.ct; int cy = t.ct >= a.cout_tiles ? 1 : 0; t.ct -= cy * a.cout_tiles;
+        t.tx += dstep.tx + cy; cy = t.tx >= a.tiles_x ? 1 : 0; t.tx -= cy * a.tiles_x;
+        t.ty += dstep.ty + cy; cy = t.ty >= a.tiles_y ? 1 : 0; t.ty -= cy * a.tiles_y;
+        t.n += dstep.n + cy;
+        return t;
+    };
 
     // ---- tile-invariant per-lane DMA byte offsets (wu_common.h, wu_dma16b): LDS slot i = piece*64 + lane ----
     // halo: pixel p = i >> 2 = (hy, hx) relative to the halo origin (oh0-1, ow0-1), LDS 16-B slot sl = i & 3 holds channel
@@ -115,14 +136,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
     unsigned hv[Q::NH];
     wu_rsrc_t rs_x = wu_make_rsrc(a.x, 0), rs_w = rs_x;
     unsigned so_tile = 0;
-    auto set_fetch_tile = [&](int tile) __attribute__((always_inline)) {
-        int tt = tile, ct;
-        if (a.ct_slowest) { const int per = a.ntiles / a.cout_tiles; ct = tt / per; tt -= ct * per; }
-        else { ct = tt % a.cout_tiles; tt /= a.cout_tiles; }
-        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
-        const int ty = tt % a.tiles_y;
-        const int n = tt / a.tiles_y;
-        const int oh0 = ty * K::TH, ow0 = tx * K::TW;
+    auto set_fetch_tile = [&](const Tc& t) __attribute__((always_inline)) {
+        const int ct = t.ct, n = t.n;
+        const int oh0 = t.ty * K::TH, ow0 = t.tx * K::TW;
         // may point before the tensor for n = 0: never dereferenced (the lanes that would are out of range below)
         rs_x = wu_make_rsrc(a.x + ((long long)n * a.H * a.W - (a.W + 1)) * a.ldx, x_img_bytes);
         rs_w = wu_make_rsrc(a.w + (size_t)ct * 64 * a.Cin, (unsigned)(((size_t)9 * a.Cout - (size_t)ct * 64) * a.Cin * 2));
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) b_lane[ks] = K::H_BYTES + l31 * 64 + (((2 * ks + lh) ^ ((l31 >> 2) & 3)) << 4);
 
-    unsigned long long t_wait = 0, t_comp = 0, t_epi_b1 = 0, t_epi_b2 = 0, t_epi_s = 0, t_mark = 0;
+    unsigned long long t_wait = 0, t_comp = 0, t_comp_rest = 0, t_epi_b1 = 0, t_epi_b2 = 0, t_epi_s = 0, t_mark = 0;
 #define WU_STAMP(acc_var) do { if (a.dbg) { const unsigned long long t_ = __builtin_readcyclecounter(); acc_var += t_ - t_mark; t_mark = t_; } } while (0)
     unsigned long long t_k0 = 0, t_r0 = 0;
     if (a.dbg) { t_mark = __builtin_readcyclecounter(); t_k0 = t_mark; t_r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -171,7 +187,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
     const int nchunks = a.Cin / 32;
     int buf = 0;                                  // LDS buffer holding the chunk being computed
     bool stores_in_flight = false;                // true after an epilogue whose NST store instructions all issued
-    set_fetch_tile(t_begin);
+    Tc cur = decode(t_begin), fetch = cur;
+    set_fetch_tile(fetch);
 #pragma unroll
     for (int j = 0; j < Q::NP; ++j) issue_piece(j, 0, 0);
 
@@ -208,23 +225,18 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
             __syncthreads();     // ... and so have everyone else's; everyone is also done with the other buffer
             WU_STAMP(t_epi_b2);  // (diagnostic) chunk-top barrier time is folded into the 'barrier2' slot
             if (c == 0) {
-                const int ct_ = a.ct_slowest ? tile / (a.ntiles / a.cout_tiles) : tile % a.cout_tiles;
+                const int ct_ = cur.ct;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
                         bvq[ni][g] = a.bias ? *(const float4*)(a.bias + ct_ * 64 + 32 * ni + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (last && more) set_fetch_tile(tile + t_step);
+            if (last && more) { fetch = advance(fetch); set_fetch_tile(fetch); }
             // the gate values of this tile's outputs are requested at the start of its LAST chunk: they land under the MFMAs
             // instead of stalling every store of the epilogue (out-of-image pixels are clamped, their stores are skipped)
             if (last && a.egate) {
-                int tt_ = tile, ct_;
-                if (a.ct_slowest) { const int per = a.ntiles / a.cout_tiles; ct_ = tt_ / per; tt_ -= ct_ * per; }
-                else { ct_ = tt_ % a.cout_tiles; tt_ /= a.cout_tiles; }
-                const int tx_ = tt_ % a.tiles_x; tt_ /= a.tiles_x;
-                const int ty_ = tt_ % a.tiles_y;
-                const int n_ = tt_ / a.tiles_y;
+                const int ct_ = cur.ct, tx_ = cur.tx, ty_ = cur.ty, n_ = cur.n;
 #pragma unroll
                 for (int mi = 0; mi < Q::RPW; ++mi) {
                     const int oh = min(ty_ * K::TH + Q::RPW * wave + mi, a.H - 1), ow = min(tx_ * K::TW + l31, a.W - 1);
@@ -306,18 +318,13 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                 }
             }
             buf = nxt;
-            WU_STAMP(t_comp);
+            if (c == 0) WU_STAMP(t_comp); else WU_STAMP(t_comp_rest);
         }
 
         // ---- epilogue of this tile (its last chunk sat in buffer buf^1, now free; buffer `buf` is receiving the next
         //      tile's chunk 0): bias + activation in fp32, [pixel][cout] image through LDS, 16-B coalesced stores ----
-        int tt = tile, ct;
-        if (a.ct_slowest) { const int per = a.ntiles / a.cout_tiles; ct = tt / per; tt -= ct * per; }
-        else { ct = tt % a.cout_tiles; tt /= a.cout_tiles; }
-        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
-        const int ty = tt % a.tiles_y;
-        const int n = tt / a.tiles_y;
-        const int oh0 = ty * K::TH, ow0 = tx * K::TW, co0 = ct * 64;
+        const int n = cur.n;
+        const int oh0 = cur.ty * K::TH, ow0 = cur.tx * K::TW, co0 = cur.ct * 64;
         // Direct epilogue, no LDS and no workgroup barrier: bias + activation in fp32, bf16 packing, then one
         // v_permlane32_swap per dword pairs the two half-waves' 8-byte channel groups into 16 contiguous bytes per lane
         // (lanes 0-31: channels 8k..8k+7 of their pixel, lanes 32-63: 8k+8..8k+15) -> 16-byte stores straight from registers.
@@ -385,12 +392,13 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         // interior tile: every lane issued all NST stores (the counted vmcnt wait at the next chunk top relies on it)
         stores_in_flight = oh0 + K::TH <= a.H && ow0 + K::TW <= a.W;
         WU_STAMP(t_epi_s);
+        cur = advance(cur);
     }
     if (NW == 4) dma_wait_all();     // the killed pieces of the last chunk still write LDS: drain before the LDS is released
     if (a.dbg && lane == 0) {
         unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
-        d[0] = t_wait; d[1] = t_comp; d[2] = __builtin_readcyclecounter() - t_k0; d[3] = __builtin_amdgcn_s_memrealtime() - t_r0;   // in-kernel clock = d2 / d3 * 100 MHz
-         d[4] = t_epi_b2; d[5] = t_epi_s; d[6] = (unsigned long long)((t_end - t_begin + t_step - 1) / t_step); d[7] = nchunks;
+        d[0] = t_wait; d[1] = t_comp + t_comp_rest; d[2] = __builtin_readcyclecounter() - t_k0; d[3] = __builtin_amdgcn_s_memrealtime() - t_r0;   // in-kernel clock = d2 / d3 * 100 MHz
+         d[4] = t_epi_b2; d[5] = t_epi_s; d[6] = (unsigned long long)((t_end - t_begin + t_step - 1) / t_step); d[7] = nchunks | (t_comp << 8);     // bits 8..: compute time of the tiles' FIRST chunks (diagnostic)
     }
 #undef WU_STAMP
 }
@@ -410,7 +418,6 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     a.ldx = ldx; a.ldy = ldy; a.ldegate = ldegate; a.egate_act = egate_act; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act;
     a.tiles_x = cdiv(W, K::TW); a.tiles_y = cdiv(H, K::TH); a.cout_tiles = Cout / 64;
     a.dbg = (unsigned long long*)g_wu_dbg_ptr;
-    a.ct_slowest = g_wu_opt[WU_OPT_CONV_CT_SLOWEST];
     a.prio_mode = g_wu_opt[WU_OPT_CONV_PRIO];
     a.strided = g_wu_opt[WU_OPT_CONV_STRIDED];
     const long long ntiles = (long long)N * a.tiles_x * a.tiles_y * a.cout_tiles;
