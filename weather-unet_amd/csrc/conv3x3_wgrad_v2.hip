@@ -176,11 +176,22 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wgrad_v2_kernel(const W2Args 
     const unsigned x_img_bytes = (unsigned)((((size_t)a.H * a.W + a.W) * a.ldx + 64) * 2);
     wu_rsrc_t rs_dy = wu_make_rsrc(a.dy, 0), rs_x = rs_dy;
     unsigned so_dy = 0, so_x = 0, border_f = 0;
-    auto set_fetch_tile = [&](int tile) __attribute__((always_inline)) {
-        int tt = tile;
-        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
-        const int ty = tt % a.tiles_y;
-        const int n = tt / a.tiles_y;
+    // fetch-tile coordinates carried incrementally (tiles of a split are consecutive): one division-based decode per
+    // workgroup, then +1 with carries (the per-tile div/mod pairs were ~100 VALU instructions per tile and wave)
+    int f_tx = 0, f_ty = 0, f_n = 0;
+    {
+        int tt = t_begin;
+        f_tx = tt % a.tiles_x; tt /= a.tiles_x;
+        f_ty = tt % a.tiles_y;
+        f_n = tt / a.tiles_y;
+    }
+    auto set_fetch_tile = [&](bool step) __attribute__((always_inline)) {
+        if (step) {
+            ++f_tx;
+            if (f_tx == a.tiles_x) { f_tx = 0; ++f_ty; }
+            if (f_ty == a.tiles_y) { f_ty = 0; ++f_n; }
+        }
+        const int tx = f_tx, ty = f_ty, n = f_n;
         const int oh0 = ty * C::TH, ow0 = tx * 32;
         rs_dy = wu_make_rsrc(a.dy + (size_t)n * a.H * a.W * a.lddy + cob * 64, dy_img_bytes);
         so_dy = (unsigned)__builtin_amdgcn_readfirstlane((oh0 * a.W + ow0) * a.lddy * 2);
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wgrad_v2_kernel(const W2Args 
     auto tile_loop = [&](auto hf_tag) __attribute__((always_inline)) {
         constexpr int HF = decltype(hf_tag)::value;
         if (t_begin < t_end) {
-            set_fetch_tile(t_begin);
+            set_fetch_tile(false);
 #pragma unroll
             for (int j = 0; j < Q::NDY + Q::NX; ++j) issue_piece(j, 0);
         }
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wgrad_v2_kernel(const W2Args 
             __syncthreads();      // ... and everyone else's; every wave is also done reading the other buffer
             WU_STAMP(t_bar);
             const bool more = tile + 1 < t_end;
-            if (more) set_fetch_tile(tile + 1);
+            if (more) set_fetch_tile(true);
             if (more && !a.dma_interleave) {
 #pragma unroll
                 for (int j = 0; j < Q::NDY + Q::NX; ++j) issue_piece(j, buf ^ 1);
