@@ -123,8 +123,12 @@ int wu_conv3x3_c3_fwd(const float* x_nchw, const float* w_oihw, const float* bia
                       int dtype, void* stream);
 /* its weight/bias gradient (the image needs no data gradient in the generator); dy NHWC or NCHW fp32 */
 int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy, int dy_nchw, const void* y, int ldy_,
-                        int act, float* dw_oihw, float* dbias, int N, int H, int W, int Cout, int stride,
-                        int accumulate, int dtype, void* stream);
+                        int act, float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes,
+                        int N, int H, int W, int Cout, int stride, int accumulate, int dtype, void* stream);
+/* Bytes of caller-owned scratch that make the two thin-layer weight gradients (wu_conv3x3_c3_wgrad on its bf16 64-channel
+ * path, wu_conv1x1_tanh_bwd) bitwise reproducible: per-workgroup partial sums land there and are folded in a fixed order.
+ * Passing workspace = NULL (or a smaller size) selects fp32 atomics across workgroups instead (last-bit run-to-run noise). */
+size_t wu_thin_workspace_bytes(void);
 /* data gradient wrt the NCHW fp32 image (needed when D is differentiated wrt G's output,
  * t_cls_train.py:243,272): dx_nchw (N,3,H,W) fp32. */
 int wu_conv3x3_c3_dgrad(const void* dy, int lddy, int dy_nchw, const void* y, int ldy_, int act,
@@ -137,8 +141,8 @@ int wu_conv1x1_tanh_fwd(const void* x, int ldx, const float* w, const float* bia
                         int N, int H, int W, int Cin, int dtype, void* stream);
 /* backward: g = dout*(1-out^2); dx = W^T g (NHWC ld=lddx) [* act'(x) if x_gate_act]; dw (+)= g x^T; dbias (+)= sum g. */
 int wu_conv1x1_tanh_bwd(const float* dout_nchw, const float* out_nchw, const void* x, int ldx, const float* w,
-                        void* dx, int lddx, float* dw, float* dbias, int N, int H, int W, int Cin,
-                        int accumulate, int x_gate_act, int dtype, void* stream);
+                        void* dx, int lddx, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                        int N, int H, int W, int Cin, int accumulate, int x_gate_act, int dtype, void* stream);
 
 /* ---- glue ------------------------------------------------------------------------------------
  * nn.MaxPool2d(2) (cunet.py:27; calls :46,49,52).  x (N,H,W,C) -> y (N,H/2,W/2,C). */

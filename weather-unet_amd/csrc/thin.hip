@@ -293,6 +293,27 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_kernel(const float* __re
     }
 }
 
+// Deterministic combination of per-workgroup partial sums: slab[nblk][stride] -> out0[0..n0) (+ out1[0..n1) from offset n0),
+// summed over the workgroups in index order (4 independent chains for load-level parallelism, combined in a fixed tree).
+constexpr int kC3Slab = 64 * 27 + 64;        // dW (1728) + dbias (64) per workgroup of conv3x3_c3_wgrad_mfma_kernel
+constexpr int kC1Slab = 3 * 64 + 3;          // dW (192) + dbias (3) per workgroup of conv1x1_tanh_bwd_kernel
+constexpr int kThinMaxBlocks = 1024;
+__global__ __launch_bounds__(256) void thin_fold_kernel(const float* __restrict__ slab, int nblk, int stride, float* __restrict__ out0, int n0,
+                                                        float* __restrict__ out1, int n1, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n0 + n1) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= nblk; b += 4) {
+        a0 += slab[(size_t)b * stride + i]; a1 += slab[(size_t)(b + 1) * stride + i];
+        a2 += slab[(size_t)(b + 2) * stride + i]; a3 += slab[(size_t)(b + 3) * stride + i];
+    }
+    for (; b < nblk; ++b) a0 += slab[(size_t)b * stride + i];
+    const float v = (a0 + a1) + (a2 + a3);
+    if (i < n0) out0[i] = accumulate ? out0[i] + v : v;
+    else if (out1) out1[i - n0] = accumulate ? out1[i - n0] + v : v;
+}
+
 // bf16 production path of the weight gradient above: dW[64 co][27 -> 32 k] = dY'^T [64 x P] * patch [P x 32] on the
 // matrix cores.  Per 256-pixel tile (linear pixel order, any image shape) the gated dY' tile and a per-pixel
 // 27-element patch row (bf16, padded to 32) are staged in LDS; both MFMA operands have the pixel (K) as their
@@ -302,7 +323,7 @@ template <int STRIDE>
 __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, int lddy,
                                                                     const bf16_t* __restrict__ y, int ldy, int act,
                                                                     float* __restrict__ dw, float* __restrict__ dbias,
-                                                                    int N, int H, int W) {
+                                                                    float* __restrict__ part, int N, int H, int W) {
     __shared__ __attribute__((aligned(16))) char smem[256 * 128 + 256 * 64];
     char* dy_lds = smem;                 // [256 px][64 co] bf16, 64-B halves swapped on odd pixel pairs
     char* pa_lds = smem + 256 * 128;     // [256 px][32 k] bf16
@@ -405,7 +426,8 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_mfma_kernel(const float*
         const float s = red[(0 * 32 + reg) * 64 + ln] + red[(1 * 32 + reg) * 64 + ln] + red[(2 * 32 + reg) * 64 + ln] + red[(3 * 32 + reg) * 64 + ln];
         const int m = reg >> 4, i = reg & 15;
         const int co = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5), k = ln & 31;
-        if (k < 27) atomicAdd(&dw[co * 27 + k], s);
+        // part != NULL: this workgroup's slice of the partial-sum slab (summed in fixed order by thin_fold_kernel)
+        if (k < 27) { if (part) part[(size_t)blockIdx.x * kC3Slab + co * 27 + k] = s; else atomicAdd(&dw[co * 27 + k], s); }
     }
     if (dbias) {
         __syncthreads();
@@ -415,7 +437,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_mfma_kernel(const float*
         if (tid < 64) {
             float sb = 0.f;
             for (int j = 0; j < 32; ++j) sb += red[(j * 8 + (tid >> 3)) * 8 + (tid & 7)];
-            atomicAdd(&dbias[tid], sb);
+            if (part) part[(size_t)blockIdx.x * kC3Slab + 1728 + tid] = sb; else atomicAdd(&dbias[tid], sb);
         }
     }
 }
@@ -657,13 +679,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv1x1_tanh_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                                const T* __restrict__ x, int ldx, const float* __restrict__ w,
                                                                T* __restrict__ dx, int lddx, float* __restrict__ dw, float* __restrict__ dbias,
-                                                               int N, int HW, int Cin, int x_gate_act) {
+                                                               float* __restrict__ part, int N, int HW, int Cin, int x_gate_act) {
     constexpr int E = ElemTraits<T>::kPer16B;
-    __shared__ float red[3][65];      // [k][channel] + [k][64] = bias
+    // per-thread partials are combined in a FIXED order: thread t owns (k, channel) and walks the pixel groups 0, 1, 2, ...
+    __shared__ float pl[256][3 * E + 1];
+    __shared__ float pb[64][3];
     const int LP = Cin / E;
     const int tid = threadIdx.x, cl = tid % LP;
-    for (int i = tid; i < 3 * 65; i += 256) (&red[0][0])[i] = 0.f;
-    __syncthreads();
     float wr[3][E], aw[3][E], ab[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -696,12 +718,22 @@ __global__ __launch_bounds__(256) void conv1x1_tanh_bwd_kernel(const float* __re
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) atomicAdd(&red[k][cl * E + e], aw[k][e]);
-        if (cl == 0) atomicAdd(&red[k][64], ab[k]);
+        for (int e = 0; e < E; ++e) pl[tid][k * E + e] = aw[k][e];
+        if (cl == 0) pb[tid / LP][k] = ab[k];
     }
     __syncthreads();
-    for (int i = tid; i < 3 * Cin; i += 256) atomicAdd(&dw[i], red[i / Cin][i % Cin]);
-    if (tid < 3) atomicAdd(&dbias[tid], red[tid][64]);
+    if (tid < 3 * Cin) {             // Cin == 64: 192 threads
+        const int k = tid / Cin, c = tid - k * Cin, ccl = c / E, e = c - ccl * E;
+        float sacc = 0.f;
+        for (int pg = 0; pg < ppi; ++pg) sacc += pl[pg * LP + ccl][k * E + e];
+        // part != NULL: this workgroup's slice of the partial-sum slab (summed in fixed order by thin_fold_kernel)
+        if (part) part[(size_t)blockIdx.x * kC1Slab + tid] = sacc; else atomicAdd(&dw[tid], sacc);
+    }
+    if (tid < 3) {
+        float sacc = 0.f;
+        for (int pg = 0; pg < ppi; ++pg) sacc += pb[pg][tid];
+        if (part) part[(size_t)blockIdx.x * kC1Slab + 3 * Cin + tid] = sacc; else atomicAdd(&dbias[tid], sacc);
+    }
 }
 
 inline int grid_cap(long long work_items, int per_block, int cap) {
@@ -751,24 +783,31 @@ extern "C" int wu_conv3x3_c3_fwd(const float* x_nchw, const float* w_oihw, const
     return 0;
 }
 
+extern "C" size_t wu_thin_workspace_bytes(void) { return (size_t)kThinMaxBlocks * kC3Slab * sizeof(float); }
+
 extern "C" int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy, int dy_nchw, const void* y, int ldy_,
-                                   int act, float* dw_oihw, float* dbias, int N, int H, int W, int Cout, int stride,
-                                   int accumulate, int dtype, void* stream) {
+                                   int act, float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes,
+                                   int N, int H, int W, int Cout, int stride, int accumulate, int dtype, void* stream) {
     WU_REQUIRE(stride == 1 || stride == 2, "conv3x3_c3_wgrad: stride");
     WU_REQUIRE(Cout > 0 && dw_oihw, "conv3x3_c3_wgrad: bad args");
     hipStream_t s = (hipStream_t)stream;
-    if (!accumulate) {
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const bool mfma_path = !dy_nchw && dtype == WU_BF16 && Cout == 64 && ((uintptr_t)dy % 16) == 0 && (lddy % 8) == 0 &&
+                           (!y || (((uintptr_t)y % 16) == 0 && (ldy_ % 8) == 0));
+    // deterministic mode: the production (bf16, 64-channel) path with a caller-owned slab for the per-workgroup partials
+    float* part = (mfma_path && workspace && workspace_bytes >= wu_thin_workspace_bytes() && ((uintptr_t)workspace % 16) == 0) ? (float*)workspace : nullptr;
+    if (!accumulate && !part) {
         hipMemsetAsync(dw_oihw, 0, (size_t)Cout * 27 * sizeof(float), s);
         if (dbias) hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
     }
-    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     dim3 grid(grid_cap((long long)N * Ho * Wo, 64, 1024), cdiv(Cout, 64));
 #define C3W(T, ST, NCHW) hipLaunchKernelGGL((conv3x3_c3_wgrad_kernel<T, ST, NCHW>), grid, dim3(256), 0, s, x_nchw, dy, lddy, y, ldy_, act, dw_oihw, dbias, N, H, W, Cout)
-    if (!dy_nchw && dtype == WU_BF16 && Cout == 64 && ((uintptr_t)dy % 16) == 0 && (lddy % 8) == 0 && (!y || (((uintptr_t)y % 16) == 0 && (ldy_ % 8) == 0))) {
+    if (mfma_path) {
         const long long ntiles = ((long long)N * Ho * Wo + 255) / 256;
-        const int g = (int)(ntiles < 1024 ? ntiles : 1024);
-        if (stride == 1) hipLaunchKernelGGL(conv3x3_c3_wgrad_mfma_kernel<1>, dim3(g), dim3(256), 0, s, x_nchw, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy_, act, dw_oihw, dbias, N, H, W);
-        else hipLaunchKernelGGL(conv3x3_c3_wgrad_mfma_kernel<2>, dim3(g), dim3(256), 0, s, x_nchw, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy_, act, dw_oihw, dbias, N, H, W);
+        const int g = (int)(ntiles < kThinMaxBlocks ? ntiles : kThinMaxBlocks);
+        if (stride == 1) hipLaunchKernelGGL(conv3x3_c3_wgrad_mfma_kernel<1>, dim3(g), dim3(256), 0, s, x_nchw, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy_, act, dw_oihw, dbias, part, N, H, W);
+        else hipLaunchKernelGGL(conv3x3_c3_wgrad_mfma_kernel<2>, dim3(g), dim3(256), 0, s, x_nchw, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy_, act, dw_oihw, dbias, part, N, H, W);
+        if (part) hipLaunchKernelGGL(thin_fold_kernel, dim3(cdiv(kC3Slab, 256)), dim3(256), 0, s, part, g, kC3Slab, dw_oihw, 1728, dbias, 64, accumulate);
         WU_LAUNCH_CHECK("conv3x3_c3_wgrad_mfma");
         return 0;
     }
@@ -831,21 +870,24 @@ extern "C" int wu_conv1x1_tanh_fwd(const void* x, int ldx, const float* w, const
 }
 
 extern "C" int wu_conv1x1_tanh_bwd(const float* dout_nchw, const float* out_nchw, const void* x, int ldx, const float* w,
-                                   void* dx, int lddx, float* dw, float* dbias, int N, int H, int W, int Cin,
-                                   int accumulate, int x_gate_act, int dtype, void* stream) {
+                                   void* dx, int lddx, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                                   int N, int H, int W, int Cin, int accumulate, int x_gate_act, int dtype, void* stream) {
     const int esz = dtype == WU_BF16 ? 2 : 4;
     const int E = 16 / esz;
     const int LP = Cin / E;
     WU_REQUIRE(Cin == 64, "conv1x1_tanh_bwd: Cin must be 64 (got %d)", Cin);
     WU_REQUIRE(((uintptr_t)x % 16) == 0 && (ldx * esz) % 16 == 0 && ((uintptr_t)dx % 16) == 0 && (lddx * esz) % 16 == 0, "conv1x1_tanh_bwd: alignment");
     hipStream_t s = (hipStream_t)stream;
-    if (!accumulate) {
+    // deterministic mode (caller-owned slab for the per-workgroup partials); otherwise fp32 atomics across workgroups
+    float* part = (workspace && workspace_bytes >= (size_t)kThinMaxBlocks * kC1Slab * sizeof(float) && ((uintptr_t)workspace % 16) == 0) ? (float*)workspace : nullptr;
+    if (!accumulate && !part) {
         hipMemsetAsync(dw, 0, (size_t)3 * Cin * sizeof(float), s);
         hipMemsetAsync(dbias, 0, 3 * sizeof(float), s);
     }
-    const int grid = grid_cap((long long)N * H * W, 256 / LP, 1024);
-    if (dtype == WU_BF16) hipLaunchKernelGGL(conv1x1_tanh_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, dout_nchw, out_nchw, (const bf16_t*)x, ldx, w, (bf16_t*)dx, lddx, dw, dbias, N, H * W, Cin, x_gate_act);
-    else hipLaunchKernelGGL(conv1x1_tanh_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, dout_nchw, out_nchw, (const float*)x, ldx, w, (float*)dx, lddx, dw, dbias, N, H * W, Cin, x_gate_act);
+    const int grid = grid_cap((long long)N * H * W, 256 / LP, kThinMaxBlocks);
+    if (dtype == WU_BF16) hipLaunchKernelGGL(conv1x1_tanh_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, dout_nchw, out_nchw, (const bf16_t*)x, ldx, w, (bf16_t*)dx, lddx, dw, dbias, part, N, H * W, Cin, x_gate_act);
+    else hipLaunchKernelGGL(conv1x1_tanh_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, dout_nchw, out_nchw, (const float*)x, ldx, w, (float*)dx, lddx, dw, dbias, part, N, H * W, Cin, x_gate_act);
+    if (part) hipLaunchKernelGGL(thin_fold_kernel, dim3(1), dim3(256), 0, s, part, grid, kC1Slab, dw, 3 * Cin, dbias, 3, accumulate);
     WU_LAUNCH_CHECK("conv1x1_tanh_bwd");
     return 0;
 }

@@ -39,10 +39,11 @@ SIGNATURES = {
     "wu_conv3x3_s2_dgrad": (I, [P, I, P, I, I, P, P, I, P, SZ, P, I, I, I, I, I, I, I, I, P]),
     "wu_act_gate": (I, [P, I, P, I, P, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_c3_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
-    "wu_conv3x3_c3_wgrad": (I, [P, P, I, I, P, I, I, P, P, I, I, I, I, I, I, I, P]),
+    "wu_conv3x3_c3_wgrad": (I, [P, P, I, I, P, I, I, P, P, P, SZ, I, I, I, I, I, I, I, P]),
+    "wu_thin_workspace_bytes": (SZ, []),
     "wu_conv3x3_c3_dgrad": (I, [P, I, I, P, I, I, P, P, P, I, I, I, I, I, I, I, P]),
     "wu_conv1x1_tanh_fwd": (I, [P, I, P, P, P, I, I, I, I, I, P]),
-    "wu_conv1x1_tanh_bwd": (I, [P, P, P, I, P, P, I, P, P, I, I, I, I, I, I, I, P]),
+    "wu_conv1x1_tanh_bwd": (I, [P, P, P, I, P, P, I, P, P, P, SZ, I, I, I, I, I, I, I, P]),
     "wu_maxpool2_fwd": (I, [P, I, P, I, I, I, I, I, I, P]),
     "wu_maxpool2_bwd": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I, P]),
     "wu_adain_style_fwd": (I, [P, P, P, F, P, P, P, I, I, I, P]),

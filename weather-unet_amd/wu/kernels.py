@@ -94,8 +94,10 @@ def conv3x3_c3_wgrad(x_nchw, gy, dw, db, stride, code, dy_nchw=False, y=None, ac
     else:
         ldg = nhwc_ld(gy)
         yp, yld = _pl(y)
+    ws = workspace(_lib.load().wu_thin_workspace_bytes(), x_nchw.device)      # deterministic partial-sum slab
     _lib.call("wu_conv3x3_c3_wgrad", x_nchw.data_ptr(), gy.data_ptr(), ldg, 1 if dy_nchw else 0, yp, yld, act,
-              dw.data_ptr(), db.data_ptr() if db is not None else None, n, h, w, cout, stride, 1 if accumulate else 0, code, stream_ptr())
+              dw.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
+              n, h, w, cout, stride, 1 if accumulate else 0, code, stream_ptr())
 
 
 def conv3x3_c3_dgrad(gy, weight, dx_nchw, stride, code, dy_nchw=False, y=None, act=ACT_NONE, accumulate=False):
@@ -170,9 +172,10 @@ def conv1x1_tanh(x, w3c, bias, out_nchw):
 
 def conv1x1_tanh_bwd(gout, out, x, w3c, dx, dw, db, x_gate_act=ACT_NONE, accumulate=False):
     n, cin, h, w = x.shape
+    ws = workspace(_lib.load().wu_thin_workspace_bytes(), x.device)           # deterministic partial-sum slab
     _lib.call("wu_conv1x1_tanh_bwd", gout.data_ptr(), out.data_ptr(), x.data_ptr(), nhwc_ld(x), w3c.data_ptr(),
-              dx.data_ptr(), nhwc_ld(dx), dw.data_ptr(), db.data_ptr(), n, h, w, cin, 1 if accumulate else 0, x_gate_act,
-              dtype_code(x), stream_ptr())
+              dx.data_ptr(), nhwc_ld(dx), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
+              n, h, w, cin, 1 if accumulate else 0, x_gate_act, dtype_code(x), stream_ptr())
 
 
 def pack_conv3x3(weight, code):
