@@ -300,18 +300,25 @@ constexpr int kC1Slab = 3 * 64 + 3;          // dW (192) + dbias (3) per workgro
 constexpr int kThinMaxBlocks = 1024;
 __global__ __launch_bounds__(256) void thin_fold_kernel(const float* __restrict__ slab, int nblk, int stride, float* __restrict__ out0, int n0,
                                                         float* __restrict__ out1, int n1, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n0 + n1) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= nblk; b += 4) {
-        a0 += slab[(size_t)b * stride + i]; a1 += slab[(size_t)(b + 1) * stride + i];
-        a2 += slab[(size_t)(b + 2) * stride + i]; a3 += slab[(size_t)(b + 3) * stride + i];
+    // 8 outputs x 32 segments per workgroup: segment s sums workgroups s, s+32, ... (independent loads), the 32 segment sums
+    // are combined in segment order through LDS -> deterministic, and ~1000 partials per output no longer sit on one thread
+    __shared__ float red[32][8];
+    const int oi = threadIdx.x & 7, seg = threadIdx.x >> 3;
+    const int i = blockIdx.x * 8 + oi;
+    float a = 0.f;
+    if (i < n0 + n1) {
+#pragma unroll 4
+        for (int b = seg; b < nblk; b += 32) a += slab[(size_t)b * stride + i];
     }
-    for (; b < nblk; ++b) a0 += slab[(size_t)b * stride + i];
-    const float v = (a0 + a1) + (a2 + a3);
-    if (i < n0) out0[i] = accumulate ? out0[i] + v : v;
-    else if (out1) out1[i - n0] = accumulate ? out1[i - n0] + v : v;
+    red[seg][oi] = a;
+    __syncthreads();
+    if (seg == 0 && i < n0 + n1) {
+        float v = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < 32; ++s_) v += red[s_][oi];
+        if (i < n0) out0[i] = accumulate ? out0[i] + v : v;
+        else if (out1) out1[i - n0] = accumulate ? out1[i - n0] + v : v;
+    }
 }
 
 // bf16 production path of the weight gradient above: dW[64 co][27 -> 32 k] = dY'^T [64 x P] * patch [P x 32] on the
@@ -341,49 +348,53 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_mfma_kernel(const float*
     for (int e = 0; e < 8; ++e) bs8[e] = 0.f;
     const int g16 = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, h = g16 >> 1;
 
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Register prefetch: the global loads of tile t+1 (8 dY' chunks [+ 8 gate chunks], 27 image values) are issued before the
+    // MFMAs of tile t and staged to LDS after them; every load is unconditional from clamped coordinates (a conditional
+    // load compiles to a branch with its own s_waitcnt: one serialized round trip per item).
+    uint4 dv[8], yv[8];
+    float pv[32];
+#pragma unroll
+    for (int k = 27; k < 32; ++k) pv[k] = 0.f;
+    auto fetch = [&](long long tile) __attribute__((always_inline)) {
         const long long base = tile * 256;
-        // ---- dY' tile: 2048 16-B items ----
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int item = tid + 256 * k;
-            const int r = item >> 3, s = item & 7;
-            const long long pix = base + r;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (pix < total) {
-                v = *(const uint4*)(dy + (size_t)pix * lddy + s * 8);
-                if (y) v = gate16<bf16_t>(v, *(const uint4*)(y + (size_t)pix * ldy + s * 8), act);
-            }
-            *(uint4*)(dy_lds + r * 128 + ((s * 16) ^ (((r >> 1) & 1) << 6))) = v;
+            const int r = item >> 3, s_ = item & 7;
+            const long long pc = min(base + r, total - 1);
+            dv[k] = *(const uint4*)(dy + (size_t)pc * lddy + s_ * 8);
+            if (y) yv[k] = *(const uint4*)(y + (size_t)pc * ldy + s_ * 8);
         }
-        // ---- patch rows: thread = pixel ----
-        {
-            const long long pix = base + tid;
-            float pv[32];
+        const long long pc = min(base + tid, total - 1);
+        const long long rowi = pc / Wo;
+        const int ow = (int)(pc - rowi * Wo), n = (int)(rowi / Ho), oh = (int)(rowi - (long long)n * Ho);
+        const float* xn = x + (size_t)n * 3 * H * W;
 #pragma unroll
-            for (int k = 27; k < 32; ++k) pv[k] = 0.f;
-            {
-                // 27 UNCONDITIONAL loads from clamped coordinates, zeroed afterwards: a conditional load compiles to a branch
-                // with its own s_waitcnt (27 serialized round trips per tile)
-                const long long pc = pix < total ? pix : total - 1;
-                const long long rowi = pc / Wo;
-                const int ow = (int)(pc - rowi * Wo), n = (int)(rowi / Ho), oh = (int)(rowi - (long long)n * Ho);
-                const float* xn = x + (size_t)n * 3 * H * W;
-#pragma unroll
-                for (int k = 0; k < 27; ++k) {
-                    const int ci = k / 9, t = k % 9, ih = oh * STRIDE + t / 3 - 1, iw = ow * STRIDE + t % 3 - 1;
-                    pv[k] = xn[((size_t)ci * H + min(max(ih, 0), H - 1)) * W + min(max(iw, 0), W - 1)];
-                }
-#pragma unroll
-                for (int k = 0; k < 27; ++k) {
-                    const int t = k % 9, ih = oh * STRIDE + t / 3 - 1, iw = ow * STRIDE + t % 3 - 1;
-                    pv[k] = (pix < total && ih >= 0 && ih < H && iw >= 0 && iw < W) ? pv[k] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) *(uint4*)(pa_lds + tid * 64 + c * 16) = pack16<bf16_t>(pv + 8 * c);
+        for (int k = 0; k < 27; ++k) {
+            const int ci = k / 9, t = k % 9, ih = oh * STRIDE + t / 3 - 1, iw = ow * STRIDE + t % 3 - 1;
+            const float v = xn[((size_t)ci * H + min(max(ih, 0), H - 1)) * W + min(max(iw, 0), W - 1)];
+            pv[k] = (base + tid < total && ih >= 0 && ih < H && iw >= 0 && iw < W) ? v : 0.f;
         }
+    };
+    auto stage = [&](long long tile) __attribute__((always_inline)) {
+        const long long base = tile * 256;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int item = tid + 256 * k;
+            const int r = item >> 3, s_ = item & 7;
+            uint4 v = dv[k];
+            if (y) v = gate16<bf16_t>(v, yv[k], act);
+            if (base + r >= total) v = make_uint4(0, 0, 0, 0);
+            *(uint4*)(dy_lds + r * 128 + ((s_ * 16) ^ (((r >> 1) & 1) << 6))) = v;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *(uint4*)(pa_lds + tid * 64 + c * 16) = pack16<bf16_t>(pv + 8 * c);
+    };
+    if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        stage(tile);
         __syncthreads();
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
         if (dbias) {       // 16-byte reads: 8 per thread and tile (was 64 two-byte ones)
             const int c8 = tid & 7;
 #pragma unroll
@@ -807,7 +818,7 @@ extern "C" int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy
         const int g = (int)(ntiles < kThinMaxBlocks ? ntiles : kThinMaxBlocks);
         if (stride == 1) hipLaunchKernelGGL(conv3x3_c3_wgrad_mfma_kernel<1>, dim3(g), dim3(256), 0, s, x_nchw, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy_, act, dw_oihw, dbias, part, N, H, W);
         else hipLaunchKernelGGL(conv3x3_c3_wgrad_mfma_kernel<2>, dim3(g), dim3(256), 0, s, x_nchw, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy_, act, dw_oihw, dbias, part, N, H, W);
-        if (part) hipLaunchKernelGGL(thin_fold_kernel, dim3(cdiv(kC3Slab, 256)), dim3(256), 0, s, part, g, kC3Slab, dw_oihw, 1728, dbias, 64, accumulate);
+        if (part) hipLaunchKernelGGL(thin_fold_kernel, dim3(cdiv(kC3Slab, 8)), dim3(256), 0, s, part, g, kC3Slab, dw_oihw, 1728, dbias, 64, accumulate);
         WU_LAUNCH_CHECK("conv3x3_c3_wgrad_mfma");
         return 0;
     }
@@ -887,7 +898,7 @@ extern "C" int wu_conv1x1_tanh_bwd(const float* dout_nchw, const float* out_nchw
     const int grid = grid_cap((long long)N * H * W, 256 / LP, kThinMaxBlocks);
     if (dtype == WU_BF16) hipLaunchKernelGGL(conv1x1_tanh_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, dout_nchw, out_nchw, (const bf16_t*)x, ldx, w, (bf16_t*)dx, lddx, dw, dbias, part, N, H * W, Cin, x_gate_act);
     else hipLaunchKernelGGL(conv1x1_tanh_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, dout_nchw, out_nchw, (const float*)x, ldx, w, (float*)dx, lddx, dw, dbias, part, N, H * W, Cin, x_gate_act);
-    if (part) hipLaunchKernelGGL(thin_fold_kernel, dim3(1), dim3(256), 0, s, part, grid, kC1Slab, dw, 3 * Cin, dbias, 3, accumulate);
+    if (part) hipLaunchKernelGGL(thin_fold_kernel, dim3(cdiv(kC1Slab, 8)), dim3(256), 0, s, part, grid, kC1Slab, dw, 3 * Cin, dbias, 3, accumulate);
     WU_LAUNCH_CHECK("conv1x1_tanh_bwd");
     return 0;
 }
