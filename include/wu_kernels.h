@@ -88,6 +88,12 @@ int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, const float* bi
                    const void* mask, int ldmask, int mask_act,
                    const void* egate, int ldegate, int egate_act, int dtype, void* stream);
 
+/* y = ReLU(conv3x3(x) + bias) AND pool = max_pool2d(y, 2) (floor: [N][H/2][W/2][Cout], pixel stride ldpool) in one call
+ * (cunet.py:45-46, 49-50, 53-54).  On the bf16 LDS-DMA path the conv epilogue writes the pooled tensor itself; otherwise the
+ * conv is followed by wu_maxpool2_fwd.  Same argument rules as wu_conv3x3_fwd (stride 1); H and W even. */
+int wu_conv3x3_relu_pool_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                             void* pool, int ldpool, int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+
 /* Weight + bias gradient of the conv above: dw_oihw[Cout][Cin][3][3] (+)= sum_pixels dy (x) x,
  * dbias[Cout] (+)= sum dy, with dy gated by act'(y) when `y` != NULL.  `workspace` must hold
  * wu_conv3x3_wgrad_workspace() bytes (deterministic split-K slabs).  accumulate != 0 adds into

@@ -403,3 +403,29 @@ def test_adain_style_fused():
     (std * gs.to(_dev()) + mean * gm.to(_dev())).sum().backward()
     assert (wg.grad.cpu() - w.grad).abs().max().item() <= 2e-5 * max(1.0, float(w.grad.abs().max()))
     assert (bg.grad.cpu() - b.grad).abs().max().item() <= 2e-5 * max(1.0, float(b.grad.abs().max()))
+
+
+@pytest.mark.parametrize("p", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 64, 64, 16, 32), (1, 64, 128, 24, 40), (3, 64, 64, 34, 38), (1, 256, 128, 20, 40), (2, 192, 64, 8, 8)])
+def test_conv3x3_relu_pool_fused(p, shape):
+    """cunet.py:45-46 etc.: the encoder conv's epilogue also writes max_pool2d(y, 2) (LDS-DMA bf16 path; conv + pool kernel
+    otherwise): y must equal the plain conv bit for bit and the pooled tensor must be the exact 2x2 maximum of that y."""
+    from wu import functional as WF, kernels as K
+    from wu.layout import empty_nhwc, precision_code, torch_dtype
+    n, cin, cout, h, w = shape
+    code = precision_code(p)
+    x = _round(_rand((n, cin, h, w), 81), p)
+    wt = _round(_rand((cout, cin, 3, 3), 82, -0.1, 0.1), p)
+    b = _rand((cout,), 83)
+    xg, bg = _nhwc(x, p), b.to(_dev())
+    wf, _ = K.pack_conv3x3(wt.to(_dev()), code)
+    dt = torch_dtype(code)
+    y_plain = K.conv3x3(xg, wf, bg, empty_nhwc(n, cout, h, w, dt, xg.device), 1, 1)
+    y = empty_nhwc(n, cout, h, w, dt, xg.device)
+    pool = empty_nhwc(n, cout, h // 2, w // 2, dt, xg.device)
+    K.conv3x3_relu_pool(xg, wf, bg, y, pool)
+    assert torch.equal(y, y_plain)
+    ref_pool = F.max_pool2d(y_plain.float(), 2)
+    assert torch.equal(pool.float(), ref_pool)
+    ref = F.relu(F.conv2d(x, wt, b, padding=1))
+    assert (y.float().cpu() - ref).abs().max().item() <= _tol(p, ref)

@@ -361,3 +361,29 @@ extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, cons
     WU_LAUNCH_CHECK("conv3x3_mfma");
     return 0;
 }
+
+// conv3x3 + bias + ReLU with its 2x2 max-pool from the same epilogue (cunet.py:45-46, 49-50, 53-54: every encoder block's
+// second conv feeds both the skip tensor y and max_pool2d(y)).  On the LDS-DMA path the pooled tensor is written by the conv
+// kernel itself (the stand-alone pool kernel re-reads all of y: 470 MB per B=32 step); otherwise conv, then the pool kernel.
+extern "C" int wu_conv3x3_relu_pool_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                                        void* pool, int ldpool, int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    WU_REQUIRE(pool && ldpool >= Cout && (ldpool * esz) % 16 == 0 && ((uintptr_t)pool % 16) == 0, "conv3x3_relu_pool_fwd: bad pool output");
+    WU_REQUIRE(H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "conv3x3_relu_pool_fwd: H=%d W=%d must be even (as for wu_maxpool2_fwd)", H, W);
+    hipStream_t s = (hipStream_t)stream;
+    const bool fused = g_wu_opt[WU_OPT_CONV_V2] && dtype == WU_BF16 && x && y && w_packed && N > 0 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 64 == 0 &&
+                       ldx >= Cin && ldy >= Cout && (ldx * esz) % 16 == 0 && (ldy * esz) % 16 == 0 &&
+                       ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 &&
+                       conv_v2_eligible(H, W, ldx, Cin, Cout, 1, dtype, false);
+    if (fused) {
+        wu_prof_pre(WU_FAM_CONV_FWD, s);
+        const int rc = conv_v2_launch(x, ldx, w_packed, bias, y, ldy, nullptr, 0, 0, N, H, W, Cin, Cout, WU_ACT_RELU, s, pool, ldpool);
+        WU_REQUIRE(rc == 0, "conv3x3_relu_pool_fwd: grid too large");
+        wu_prof_post(WU_FAM_CONV_FWD, s, 2.0 * N * H * W * (double)Cout * 9.0 * Cin, ((double)N * H * W * (Cin + Cout) + 9.0 * Cin * Cout) * esz);
+        WU_LAUNCH_CHECK("conv3x3_mfma_v2 (+pool)");
+        return 0;
+    }
+    const int rc = wu_conv3x3_fwd(x, ldx, w_packed, bias, y, ldy, N, H, W, Cin, Cout, 1, WU_ACT_RELU, nullptr, 0, 0, nullptr, 0, 0, dtype, stream);
+    if (rc) return rc;
+    return wu_maxpool2_fwd(y, ldy, pool, ldpool, N, H, W, Cout, dtype, stream);
+}

@@ -41,7 +41,8 @@ template <int NW_> struct KW {
 
 struct V2Args {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; const bf16_t* egate;
-    int ldx, ldy, ldegate, egate_act;
+    bf16_t* pool;                // optional: 2x2 max-pool of y (ReLU outputs), written from the same epilogue
+    int ldx, ldy, ldegate, egate_act, ldpool;
     int N, H, W, Cin, Cout, act;
     int tiles_x, tiles_y, cout_tiles, ntiles, prio_mode, strided;
     unsigned long long* dbg;     // diagnostic: per-workgroup phase cycle sums (NULL in production)
@@ -61,6 +62,11 @@ __device__ __forceinline__ uint32_t relu_gate_bf16x2(uint32_t g, uint32_t y) {
     const u16x2_t m = u16x2_t{0, 0} - nz;                                              // 0xffff where y != 0
     const s16x2_t sg = __builtin_bit_cast(s16x2_t, y) >> s16x2_t{15, 15};               // 0xffff where y < 0
     return g & __builtin_bit_cast(uint32_t, m) & ~__builtin_bit_cast(uint32_t, sg);
+}
+// max of two packed pairs of NON-NEGATIVE bf16 (they order like unsigned 16-bit integers): v_pk_max_u16
+__device__ __forceinline__ uint32_t max_u16x2(uint32_t a, uint32_t b) {
+    const u16x2_t m = __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b));
+    return __builtin_bit_cast(uint32_t, m);
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& b) {
@@ -334,63 +340,87 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         // Specialised per (activation, gate) pair -- selected once per tile -- so the body is straight packed arithmetic:
         // v_pk_add_f32 bias, v_cvt_pk_bf16_f32, ReLU as v_pk_max_i16 on the packed pair (ReLU commutes with the monotonic
         // rounding), the ReLU gate as packed 16-bit integer masks; no per-element compare / select chains.
-        auto epi_store = [&](auto act_tag, auto eg_tag) __attribute__((always_inline)) {
+        auto epi_store = [&](auto act_tag, auto eg_tag, auto pool_tag) __attribute__((always_inline)) {
             constexpr int ACT = decltype(act_tag)::value, EG = decltype(eg_tag)::value;
+            constexpr bool POOL = decltype(pool_tag)::value;       // only with ACT == RELU (non-negative outputs)
 #pragma unroll
-            for (int mi = 0; mi < Q::RPW; ++mi) {
-                const int oh = oh0 + Q::RPW * wave + mi, ow = ow0 + l31;
-                const bool ok = oh < a.H && ow < a.W;
-                const size_t pix = img_pix + (size_t)(oh * a.W + ow);
-                bf16_t* yp = a.y + pix * a.ldy + co0 + 8 * lh;
+            for (int mp = 0; mp < Q::RPW / 2; ++mp) {                // the wave's rows in vertical pairs (even, odd)
+                const int ohe = oh0 + Q::RPW * wave + 2 * mp, ow = ow0 + l31;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                     for (int g = 0; g < 4; g += 2) {
-                        uint32_t o[2][2];
+                        uint4 vr[2];
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const float4 bv = bvq[ni][g + h];
-                            const int r0 = 4 * (g + h);
-                            f32x2_t v0 = f32x2_t{acc[mi][ni][r0 + 0], acc[mi][ni][r0 + 1]} + f32x2_t{bv.x, bv.y};
-                            f32x2_t v1 = f32x2_t{acc[mi][ni][r0 + 2], acc[mi][ni][r0 + 3]} + f32x2_t{bv.z, bv.w};
-                            if (ACT == WU_ACT_LEAKY) {      // max(v, 0.2 v)
-                                const f32x2_t s0_ = v0 * 0.2f, s1_ = v1 * 0.2f;
-                                v0 = f32x2_t{fmaxf(v0.x, s0_.x), fmaxf(v0.y, s0_.y)};
-                                v1 = f32x2_t{fmaxf(v1.x, s1_.x), fmaxf(v1.y, s1_.y)};
+                        for (int r = 0; r < 2; ++r) {
+                            const int mi = 2 * mp + r;
+                            uint32_t o[2][2];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const float4 bv = bvq[ni][g + h];
+                                const int r0 = 4 * (g + h);
+                                f32x2_t v0 = f32x2_t{acc[mi][ni][r0 + 0], acc[mi][ni][r0 + 1]} + f32x2_t{bv.x, bv.y};
+                                f32x2_t v1 = f32x2_t{acc[mi][ni][r0 + 2], acc[mi][ni][r0 + 3]} + f32x2_t{bv.z, bv.w};
+                                if (ACT == WU_ACT_LEAKY) {      // max(v, 0.2 v)
+                                    const f32x2_t s0_ = v0 * 0.2f, s1_ = v1 * 0.2f;
+                                    v0 = f32x2_t{fmaxf(v0.x, s0_.x), fmaxf(v0.y, s0_.y)};
+                                    v1 = f32x2_t{fmaxf(v1.x, s1_.x), fmaxf(v1.y, s1_.y)};
+                                }
+                                o[h][0] = pack_bf16x2(v0.x, v0.y);
+                                o[h][1] = pack_bf16x2(v1.x, v1.y);
+                                if (ACT == WU_ACT_RELU) { o[h][0] = relu_bf16x2(o[h][0]); o[h][1] = relu_bf16x2(o[h][1]); }
                             }
-                            o[h][0] = pack_bf16x2(v0.x, v0.y);
-                            o[h][1] = pack_bf16x2(v1.x, v1.y);
-                            if (ACT == WU_ACT_RELU) { o[h][0] = relu_bf16x2(o[h][0]); o[h][1] = relu_bf16x2(o[h][1]); }
+                            // vdst = group g, src = group g+1 (cdna guide T21)
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(o[0][0], o[1][0], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(o[0][1], o[1][1], false, false);
+                            uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                            if (EG != WU_ACT_NONE) {
+                                const uint4 yv = egv[mi][ni][g >> 1];
+                                if (EG == WU_ACT_RELU) {
+                                    v.x = relu_gate_bf16x2(v.x, yv.x); v.y = relu_gate_bf16x2(v.y, yv.y);
+                                    v.z = relu_gate_bf16x2(v.z, yv.z); v.w = relu_gate_bf16x2(v.w, yv.w);
+                                } else {
+                                    v = gate16<bf16_t>(v, yv, WU_ACT_LEAKY);
+                                }
+                            }
+                            const int oh = ohe + r;
+                            if (oh < a.H && ow < a.W)
+                                *(uint4*)(a.y + (img_pix + (size_t)(oh * a.W + ow)) * a.ldy + co0 + 8 * lh + 32 * ni + 8 * g) = v;
+                            vr[r] = v;
                         }
-                        // vdst = group g, src = group g+1 (cdna guide T21)
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(o[0][0], o[1][0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane32_swap(o[0][1], o[1][1], false, false);
-                        uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                        if (EG != WU_ACT_NONE) {
-                            const uint4 yv = egv[mi][ni][g >> 1];
-                            if (EG == WU_ACT_RELU) {
-                                v.x = relu_gate_bf16x2(v.x, yv.x); v.y = relu_gate_bf16x2(v.y, yv.y);
-                                v.z = relu_gate_bf16x2(v.z, yv.z); v.w = relu_gate_bf16x2(v.w, yv.w);
-                            } else {
-                                v = gate16<bf16_t>(v, yv, WU_ACT_LEAKY);
+                        if (POOL) {
+                            // 2x2 max-pool (cunet.py:46,50,54) of the ReLU outputs: non-negative bf16 order like unsigned integers,
+                            // so the window maximum is v_pk_max_u16 over the row pair and over the neighbouring lane (pixel ow ^ 1)
+                            uint4 m = make_uint4(max_u16x2(vr[0].x, vr[1].x), max_u16x2(vr[0].y, vr[1].y), max_u16x2(vr[0].z, vr[1].z), max_u16x2(vr[0].w, vr[1].w));
+                            m.x = max_u16x2(m.x, (uint32_t)__builtin_amdgcn_mov_dpp((int)m.x, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+                            m.y = max_u16x2(m.y, (uint32_t)__builtin_amdgcn_mov_dpp((int)m.y, 0xB1, 0xF, 0xF, true));
+                            m.z = max_u16x2(m.z, (uint32_t)__builtin_amdgcn_mov_dpp((int)m.z, 0xB1, 0xF, 0xF, true));
+                            m.w = max_u16x2(m.w, (uint32_t)__builtin_amdgcn_mov_dpp((int)m.w, 0xB1, 0xF, 0xF, true));
+                            if ((l31 & 1) == 0 && ohe + 1 < a.H && ow + 1 < a.W) {
+                                const int Hp = a.H >> 1, Wp = a.W >> 1;
+                                *(uint4*)(a.pool + (((size_t)n * Hp + (ohe >> 1)) * Wp + (ow >> 1)) * a.ldpool + co0 + 8 * lh + 32 * ni + 8 * g) = m;
                             }
                         }
-                        if (ok) *(uint4*)(yp + 32 * ni + 8 * g) = v;
                     }
             }
         };
         using A0 = std::integral_constant<int, WU_ACT_NONE>;
         using A1 = std::integral_constant<int, WU_ACT_RELU>;
         using A2 = std::integral_constant<int, WU_ACT_LEAKY>;
+        using NoPool = std::false_type;
         if (a.egate) {                     // host guarantees act == NONE with a gate (conv_v2_eligible)
-            if (a.egate_act == WU_ACT_RELU) epi_store(A0{}, A1{});
-            else if (a.egate_act == WU_ACT_LEAKY) epi_store(A0{}, A2{});
-            else epi_store(A0{}, A0{});
-        } else if (a.act == WU_ACT_RELU) epi_store(A1{}, A0{});
-        else if (a.act == WU_ACT_LEAKY) epi_store(A2{}, A0{});
-        else epi_store(A0{}, A0{});
-        // interior tile: every lane issued all NST stores (the counted vmcnt wait at the next chunk top relies on it)
-        stores_in_flight = oh0 + K::TH <= a.H && ow0 + K::TW <= a.W;
+            if (a.egate_act == WU_ACT_RELU) epi_store(A0{}, A1{}, NoPool{});
+            else if (a.egate_act == WU_ACT_LEAKY) epi_store(A0{}, A2{}, NoPool{});
+            else epi_store(A0{}, A0{}, NoPool{});
+        } else if (a.act == WU_ACT_RELU) {
+            if (a.pool) epi_store(A1{}, A0{}, std::true_type{});      // host guarantees act == RELU with a pool output
+            else epi_store(A1{}, A0{}, NoPool{});
+        }
+        else if (a.act == WU_ACT_LEAKY) epi_store(A2{}, A0{}, NoPool{});
+        else epi_store(A0{}, A0{}, NoPool{});
+        // interior tile: every lane issued all NST stores (the counted vmcnt wait at the next chunk top relies on it); with the
+        // pool output the number of store instructions differs per wave half -> plain vmcnt(0) there
+        stores_in_flight = oh0 + K::TH <= a.H && ow0 + K::TW <= a.W && !a.pool;
         WU_STAMP(t_epi_s);
         cur = advance(cur);
     }
@@ -412,8 +442,10 @@ bool conv_v2_eligible(int H, int W, int ldx, int Cin, int Cout, int stride, int 
 }
 
 int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
-                   const void* egate, int ldegate, int egate_act, int N, int H, int W, int Cin, int Cout, int act, hipStream_t s) {
+                   const void* egate, int ldegate, int egate_act, int N, int H, int W, int Cin, int Cout, int act, hipStream_t s,
+                   void* pool, int ldpool) {
     V2Args a;
+    a.pool = (bf16_t*)pool; a.ldpool = ldpool;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.egate = (const bf16_t*)egate;
     a.ldx = ldx; a.ldy = ldy; a.ldegate = ldegate; a.egate_act = egate_act; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act;
     a.tiles_x = cdiv(W, K::TW); a.tiles_y = cdiv(H, K::TH); a.cout_tiles = Cout / 64;

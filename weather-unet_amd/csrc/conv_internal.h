@@ -3,5 +3,7 @@
 #include <hip/hip_runtime.h>
 
 bool conv_v2_eligible(int H, int W, int ldx, int Cin, int Cout, int stride, int dtype, bool masked);
+// pool != NULL (act must be ReLU, no gate): the epilogue also writes the 2x2 max-pool of y
 int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
-                   const void* egate, int ldegate, int egate_act, int N, int H, int W, int Cin, int Cout, int act, hipStream_t s);
+                   const void* egate, int ldegate, int egate_act, int N, int H, int W, int Cin, int Cout, int act, hipStream_t s,
+                   void* pool = nullptr, int ldpool = 0);

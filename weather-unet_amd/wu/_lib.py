@@ -33,6 +33,7 @@ SIGNATURES = {
     "wu_spectral_norm_bwd": (I, [P, P, P, P, P, P, I, I, P, P]),
     "wu_pack_conv3x3": (I, [P, P, P, I, I, P, I, P]),
     "wu_conv3x3_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P, I, I, P, I, I, I, P]),
+    "wu_conv3x3_relu_pool_fwd": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_wgrad_workspace": (SZ, [I, I, I, I, I, I, I]),
     "wu_conv3x3_wgrad": (I, [P, I, P, I, P, I, I, P, P, P, SZ, I, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_s2_dgrad_workspace": (SZ, [I, I, I, I, I]),

@@ -43,6 +43,15 @@ def conv3x3(x, w_packed, bias, y, stride=1, act=ACT_NONE, mask=None, mask_act=AC
     return y
 
 
+def conv3x3_relu_pool(x, w_packed, bias, y, pool):
+    """y = ReLU(conv3x3(x) + bias), pool = max_pool2d(y, 2) -- wu_conv3x3_relu_pool_fwd (fused epilogue on the bf16 path)."""
+    n, cin, h, w = x.shape
+    cout = y.shape[1]
+    _lib.call("wu_conv3x3_relu_pool_fwd", x.data_ptr(), nhwc_ld(x), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+              y.data_ptr(), nhwc_ld(y), pool.data_ptr(), nhwc_ld(pool), n, h, w, cin, cout, dtype_code(x), stream_ptr())
+    return y, pool
+
+
 def conv3x3_s2_dgrad(gy, w_dgrad, dx, y=None, act=ACT_NONE, egate=None, egate_act=ACT_NONE):
     n, cin, h, w = dx.shape
     cout = gy.shape[1]

@@ -63,14 +63,11 @@ class UNetFn(Function):
 
         # ---- encoder (cunet.py:45-54) ----
         a1 = K.conv3x3_c3(x, wb["dconv_down1"][0].detach().contiguous(), wb["dconv_down1"][1], _new(n, 64, h, w, dt, dev), 1, RELU, False, code)
-        K.conv3x3(a1, pk["dconv_down1.2"][0], wb["dconv_down1"][3], conv1, 1, RELU)
-        p1 = K.maxpool2(conv1, _new(n, 64, h // 2, w // 2, dt, dev))
+        p1 = K.conv3x3_relu_pool(a1, pk["dconv_down1.2"][0], wb["dconv_down1"][3], conv1, _new(n, 64, h // 2, w // 2, dt, dev))[1]
         a2 = K.conv3x3(p1, pk["dconv_down2.0"][0], wb["dconv_down2"][1], _new(n, 128, h // 2, w // 2, dt, dev), 1, RELU)
-        K.conv3x3(a2, pk["dconv_down2.2"][0], wb["dconv_down2"][3], conv2, 1, RELU)
-        p2 = K.maxpool2(conv2, _new(n, 128, h // 4, w // 4, dt, dev))
+        p2 = K.conv3x3_relu_pool(a2, pk["dconv_down2.2"][0], wb["dconv_down2"][3], conv2, _new(n, 128, h // 4, w // 4, dt, dev))[1]
         a3 = K.conv3x3(p2, pk["dconv_down3.0"][0], wb["dconv_down3"][1], _new(n, 256, h // 4, w // 4, dt, dev), 1, RELU)
-        K.conv3x3(a3, pk["dconv_down3.2"][0], wb["dconv_down3"][3], conv3, 1, RELU)
-        p3 = K.maxpool2(conv3, _new(n, 256, h // 8, w // 8, dt, dev))
+        p3 = K.conv3x3_relu_pool(a3, pk["dconv_down3.2"][0], wb["dconv_down3"][3], conv3, _new(n, 256, h // 8, w // 8, dt, dev))[1]
         a4 = K.conv3x3(p3, pk["dconv_down4.0"][0], wb["dconv_down4"][1], _new(n, 512, h // 8, w // 8, dt, dev), 1, RELU)
         b4 = K.conv3x3(a4, pk["dconv_down4.2"][0], wb["dconv_down4"][3], _new(n, 512, h // 8, w // 8, dt, dev), 1, RELU)
 
