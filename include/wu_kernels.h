@@ -43,8 +43,8 @@ const char* wu_last_error(void);
 int wu_version(void);
 /* Kernel-variant switches for in-process A/B benchmarking.  Defaults = production choices; results are identical either way.
  *   0: conv LDS-DMA path (0 off = generic template, 1 auto wave shape (default), 2 always 4 waves, 3 always 8 waves)
- *   1: persistent tile loop on/off      2: LDS-DMA wgrad on/off        3: cout tile slowest in the tile order (default 0)
- *   4: wgrad DMA issue spread over K-steps (default 1)   5: row-wise thin first conv (default 0)
+ *   1: persistent tile loop on/off      2: LDS-DMA wgrad (0 off, 1 = 8 waves (default), 2 = 4 waves)      3: unused
+ *   4: wgrad DMA issue spread over K-steps (default 1)   5: first conv (0 matrix cores in bf16 (default), 1 rows kernel, 2 VALU kernel)
  *   6: static priority for the younger wave half (default 1)   7: grid-strided tile assignment (default 1) */
 int wu_set_option(int key, int value);
 /* Diagnostic: device buffer of 256*8*8 uint64 receiving per-wave phase cycle sums of the persistent conv / wgrad kernels
