@@ -174,7 +174,7 @@ def main():
         # step), so the per-launch durations above include the time a kernel shares the chip.  A short extra pass with that
         # overlap switched off gives the kernels' stand-alone rate, reported next to the in-step figure.
         iso = None
-        if gan is None and not a.fwd_only:
+        if gan is None and not a.fwd_only and world == 1:     # extra steps contain collectives: single-rank runs only
             from wu import unet_graph as UG
             if UG.SIDE_STREAM_WGRAD:
                 UG.SIDE_STREAM_WGRAD = False
