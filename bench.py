@@ -45,10 +45,29 @@ def parse():
     ap.add_argument("--fwd-only", action="store_true", help="inference forward (eval mode) instead of the training step")
     ap.add_argument("--graph", action="store_true", help="with --fwd-only: replay a hipGraph-captured forward (configs[4])")
     ap.add_argument("--force-ddp", action="store_true", help="initialise RCCL and use the bucketed reducer even with one rank (test hook)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only (gloo, no GPU): every rank joins, rank 0 prints {\"launch_check\": world}; "
+                         "exercises the --gpus N self-launch path on a CPU box")
     ap.add_argument("--workload", default="unet", choices=["unet", "gan-cls", "gan-est"],
                     help="unet: cUNet fwd+bwd (the headline metric); gan-cls / gan-est: one full GAN iteration "
                          "(D update + G update) of t_cls_train.py / t_est_train.py (configs[2] / configs[3])")
     return ap.parse_args()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    args>` as a CHILD process (this parent never touches the GPU and never exec()s) and pass its output through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(size, iters=3, batch=4):
@@ -78,9 +97,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...`")
+        if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+            # plain `python bench.py --gpus N`: start the N ranks ourselves (one fresh process per GPU through the stock
+            # launcher) BEFORE this process makes any GPU call, relay rank 0's JSON line, exit with the launcher's code
+            raise SystemExit(self_launch(a.gpus))
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.launch_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": int(t.item()), "n_gpus": world}), flush=True)
+        dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -149,6 +180,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from wu import unet_graph as UG
+    UG.prepare_side_stream(dev)                # the one-off side-stream probe must not land in a timed step (warm-up may be 0)
     for _ in range(a.warmup):
         step()
     families = [_lib.FAM_CONV_FWD, _lib.FAM_WGRAD, _lib.FAM_CONV_DGRAD]

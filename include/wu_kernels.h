@@ -41,6 +41,8 @@ extern "C" {
 
 const char* wu_last_error(void);
 int wu_version(void);
+/* Compute units of the current HIP device (256 on MI355X): the persistent conv / weight-gradient grids are sized from it. */
+int wu_cu_count(void);
 /* Kernel-variant switches for in-process A/B benchmarking.  Defaults = production choices; results are identical either way.
  *   0: conv LDS-DMA path (0 off = generic template, 1 auto wave shape (default), 2 always 4 waves, 3 always 8 waves)
  *   1: persistent tile loop on/off      2: LDS-DMA wgrad (0 off, 1 = 8 waves (default), 2 = 4 waves)      3: unused
@@ -183,10 +185,15 @@ int wu_adain_stats(const void* x, int ldx, float* stats, float* scratch, int N, 
  * y_std / y_mean: (N,C) fp32 style statistics of utils.py:46,48.  p_drop == 0 -> eval mode.
  * Dropout keep-mask = counter RNG(seed, element index); keep scale 1/(1-p).  `mask_bits` (may be NULL):
  * N*2H*2W*(C / elements-per-16-B) bytes receiving one keep-bit per element, so the backward pass reads the
- * mask instead of re-hashing (pass the same pointer, or NULL to regenerate from the seed). */
+ * mask instead of re-hashing (pass the same pointer, or NULL to regenerate from the seed).
+ * `seed_dev` (may be NULL): device-resident uint64 added to `seed` inside the kernel -- a captured hipGraph freezes the
+ * `seed` argument, the counter it points to can be bumped between replays (the reference's inference loops run with
+ * Dropout ACTIVE: inference/inf_transfer_c.py:88-96 never calls .eval()).
+ * mask_is_input != 0: `mask_bits` is READ instead of drawn (an externally supplied keep-mask, e.g. one captured from the
+ * reference's own nn.Dropout, for parity tests and replays of a recorded step). */
 int wu_adain_upcat_fwd(const void* x, int ldx, const float* stats, const float* y_std, const float* y_mean,
                        void* y, int ldy, int N, int H, int W, int C, float p_drop, uint64_t seed,
-                       uint8_t* mask_bits, int dtype, void* stream);
+                       const uint64_t* seed_dev, uint8_t* mask_bits, int mask_is_input, int dtype, void* stream);
 /* Backward of the above.  dy: gradient of the concat buffer channels [0,C) (N,2H,2W) ld=lddy.
  * Produces dx (N,H,W,C) ld=lddx and d_y_std, d_y_mean (N,C) fp32.  `gtmp` (N*H*W*C elements of `dtype`) and
  * `sums` (N*C*2*(1+WU_MAX_SPLITS) floats) are caller-provided scratch.  x_gate_act != 0: dx is additionally multiplied by

@@ -128,10 +128,46 @@ def make_inputs(batch, size, num_classes=5, seed=0, soft=False):
 # generator: Conditional_UNet.forward   (cunet.py:43-82)
 # --------------------------------------------------------------------------------------
 
-def r_double_conv(p, name, x):
-    """nets.py:18-24: Conv3x3(pad 1, bias) -> ReLU -> Conv3x3 -> ReLU."""
-    x = F.relu(F.conv2d(x, p[f"{name}.0.weight"], p[f"{name}.0.bias"], padding=1))
-    x = F.relu(F.conv2d(x, p[f"{name}.2.weight"], p[f"{name}.2.bias"], padding=1))
+class _RoundBF16(torch.autograd.Function):
+    """bf16-emulation hook (NOT part of the reference's arithmetic; see cunet_forward(emulate_bf16=True)): a tensor the
+    MI355X kernels park in HBM as bf16.  Forward rounds the value to bf16 (round-to-nearest-even, kept in an fp32 tensor);
+    backward rounds the gradient that flows into it -- the kernels store that gradient tensor in bf16 too."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+class _RoundGradBF16(torch.autograd.Function):
+    """Identity forward, bf16-rounded gradient: a GRADIENT tensor the kernels park in bf16 where the forward keeps fp32."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+def _q(t, emu):
+    return _RoundBF16.apply(t) if emu else t
+
+
+def _qw(w, emu):
+    """Weights are fp32 parameters re-packed to bf16 MFMA operands; their GRADIENT stays fp32 (straight-through)."""
+    return w + (w.to(torch.bfloat16).float() - w).detach() if emu else w
+
+
+def r_double_conv(p, name, x, emu=False):
+    """nets.py:18-24: Conv3x3(pad 1, bias) -> ReLU -> Conv3x3 -> ReLU.
+    (emu: bf16 operands, fp32 accumulate + bias + ReLU, bf16 store -- the kernels' storage points.)"""
+    x = _q(F.relu(F.conv2d(x, _qw(p[f"{name}.0.weight"], emu), p[f"{name}.0.bias"], padding=1)), emu)
+    x = _q(F.relu(F.conv2d(x, _qw(p[f"{name}.2.weight"], emu), p[f"{name}.2.bias"], padding=1)), emu)
     return x
 
 
@@ -166,33 +202,44 @@ def dropout(x, mask, p=0.3):
     return x * mask.to(x.dtype) * (1.0 / (1.0 - p))
 
 
-def cunet_forward(p, x, c, masks=None, return_stages=False):
+def cunet_forward(p, x, c, masks=None, return_stages=False, emulate_bf16=False):
     """Conditional_UNet.forward (cunet.py:43-82).  ``masks`` = None (eval mode) or a list of
-    three keep-masks for the dropouts at cunet.py:61,68,75 (train mode with a known mask)."""
+    three keep-masks for the dropouts at cunet.py:61,68,75 (train mode with a known mask).
+
+    ``emulate_bf16`` (default False = the reference's fp32 arithmetic, the only mode pinned against the reference):
+    the SAME graph with every tensor that the MI355X bf16 kernels keep in HBM as bf16 rounded to bf16 at that point --
+    the input image and every conv weight as MFMA operands, each conv / pool / AdaIN-upsample-dropout output, and, through
+    autograd, the gradient of each of those tensors (the gradient w.r.t. the AdaIN output is parked in bf16 as well).
+    Accumulation, bias, activations, statistics, tanh and the weight gradients stay fp32, as in the kernels.  What is left
+    between this mode and the HIP bf16 path is summation order (and the rare last-bit rounding flips it causes): it
+    separates "bf16 precision mode" from "kernel error" in the gradient parity tests."""
+    emu = emulate_bf16
     m3, m2, m1 = masks if masks is not None else (None, None, None)
     st = {}
-    conv1 = r_double_conv(p, "dconv_down1", x)               # :45
-    x = F.max_pool2d(conv1, 2)                               # :46
-    conv2 = r_double_conv(p, "dconv_down2", x)               # :48
-    x = F.max_pool2d(conv2, 2)                               # :49
-    conv3 = r_double_conv(p, "dconv_down3", x)               # :51
-    x = F.max_pool2d(conv3, 2)                               # :52
-    x = r_double_conv(p, "dconv_down4", x)                   # :54
+    x = _q(x, emu)                                           # (emu) the image enters the first conv's MFMA as bf16
+    conv1 = r_double_conv(p, "dconv_down1", x, emu)          # :45
+    x = _q(F.max_pool2d(conv1, 2), emu)                      # :46
+    conv2 = r_double_conv(p, "dconv_down2", x, emu)          # :48
+    x = _q(F.max_pool2d(conv2, 2), emu)                      # :49
+    conv3 = r_double_conv(p, "dconv_down3", x, emu)          # :51
+    x = _q(F.max_pool2d(conv3, 2), emu)                      # :52
+    x = r_double_conv(p, "dconv_down4", x, emu)              # :54
     st.update(conv1=conv1, conv2=conv2, conv3=conv3, bottleneck=x)
-    x = adain(p, "adain3", x, c)                             # :59
+    gq = _RoundGradBF16.apply if emu else (lambda t: t)
+    x = gq(adain(p, "adain3", x, c))                         # :59
     st["adain3"] = x
-    x = torch.cat([dropout(upsample2(x), m3), conv3], dim=1)  # :60-62
-    x = r_double_conv(p, "dconv_up3", x)                     # :64
+    x = _q(torch.cat([dropout(upsample2(x), m3), conv3], dim=1), emu)  # :60-62
+    x = r_double_conv(p, "dconv_up3", x, emu)                # :64
     st["up3"] = x
-    x = adain(p, "adain2", x, c)                             # :66
+    x = gq(adain(p, "adain2", x, c))                         # :66
     st["adain2"] = x
-    x = torch.cat([dropout(upsample2(x), m2), conv2], dim=1)  # :67-69
-    x = r_double_conv(p, "dconv_up2", x)                     # :71
+    x = _q(torch.cat([dropout(upsample2(x), m2), conv2], dim=1), emu)  # :67-69
+    x = r_double_conv(p, "dconv_up2", x, emu)                # :71
     st["up2"] = x
-    x = adain(p, "adain1", x, c)                             # :73
+    x = gq(adain(p, "adain1", x, c))                         # :73
     st["adain1"] = x
-    x = torch.cat([dropout(upsample2(x), m1), conv1], dim=1)  # :74-76
-    x = r_double_conv(p, "dconv_up1", x)                     # :78
+    x = _q(torch.cat([dropout(upsample2(x), m1), conv1], dim=1), emu)  # :74-76
+    x = r_double_conv(p, "dconv_up1", x, emu)                # :78
     st["up1"] = x
     out = torch.tanh(F.conv2d(x, p["conv_last.weight"], p["conv_last.bias"]))  # :80-82
     if return_stages:
@@ -271,3 +318,75 @@ def recon_loss(fake, img, pred, r):
 def bench_loss(out, x):
     """The pure fwd+bwd benchmark's scalar loss: mean|G(x,c) - x|."""
     return torch.mean(torch.abs(out - x))
+
+
+# --------------------------------------------------------------------------------------
+# GAN step (t_cls_train.py:226-312, t_est_train.py:214-283) and evaluation() (t_cls_train.py:314-367)
+# restated on the functional generator / discriminator above; `estimator` is any callable
+# (N,3,H,W) -> (N,nc) RAW outputs (the pickled ResNet-101 of t_cls_train.py:172 is out of scope)
+# --------------------------------------------------------------------------------------
+
+def pred_loss(preds, labels, one_hot=False):
+    """ops.py:29-40: CrossEntropy on raw outputs vs class indices if one_hot (--cross_ent) else MSE."""
+    return F.cross_entropy(preds, labels) if one_hot else F.mse_loss(preds, labels)
+
+
+def update_discriminator_loss(gp, dp, estimator_out, images, labels, c_d=None, supervised=False, masks=None):
+    """t_cls_train.py:288-312 / t_est_train.py:261-283 up to d_loss.  ``estimator_out(x)`` is what the script calls
+    ``self.estimator`` (softmax head in t_cls_train :174-178, the raw regressor in t_est_train).  Returns
+    (d_loss, new_buffers_after_both_D_forwards)."""
+    pred_labels = c_d if supervised else estimator_out(images).detach()                  # :294-297
+    real, nb1 = sndisc_forward(dp, images, pred_labels, train=True)                     # :299
+    with torch.no_grad():
+        fake_out = cunet_forward(gp, images, labels, masks)                             # :302 (detached at :303)
+    dp2 = dict(dp)
+    dp2.update(nb1)
+    fake, nb2 = sndisc_forward(dp2, fake_out, labels, train=True)                       # :303
+    return dis_hinge(fake[0], real[0]), nb2                                             # :305
+
+
+def update_inference_loss(gp, dp, estimator_out, estimator_raw, images, r_labels, d_labels=None, r_labels_=None,
+                          supervised=False, cross_ent=False, masks=None):
+    """t_cls_train.py:226-270 (flags --supervised / --cross_ent) and t_est_train.py:214-245 (both flags off).
+    Returns (g_loss, g_loss_adv, loss_con, g_loss_w, g_loss_l1, fake_out)."""
+    pred_labels = d_labels if supervised else estimator_out(images).detach()            # :233-237
+    fake_out = cunet_forward(gp, images, r_labels, masks)                               # :242
+    fake_d_out = sndisc_forward(dp, fake_out, r_labels, train=True)[0][0]               # :243-244
+    if cross_ent:
+        fake_c_out = estimator_raw(fake_out)                                            # :248 last layer is not softmax
+    else:
+        fake_c_out = estimator_out(fake_out)                                            # :250
+        r_labels_ = r_labels                                                            # :251
+    g_loss_adv = gen_hinge(fake_d_out)                                                  # :254
+    g_loss_l1 = F.l1_loss(fake_out, images)                                             # :255 (logged only)
+    g_loss_w = pred_loss(fake_c_out, r_labels_, one_hot=cross_ent)                      # :256
+    diff = torch.mean(torch.abs(fake_out - images), [1, 2, 3])                          # :260,264
+    lmda = torch.mean(torch.abs(pred_labels - r_labels), 1)                             # :261,265
+    loss_con = torch.mean(diff / (lmda + (1e-2 if supervised else 1e-7)))               # :262,266
+    g_loss = g_loss_adv + loss_con + g_loss_w                                           # :268-270 (lmda_con = lmda_w = 1)
+    return g_loss, g_loss_adv, loss_con, g_loss_w, g_loss_l1, fake_out
+
+
+def evaluation(gp, dp, estimator_out, estimator_eval, images, labels, ref_labels):
+    """t_cls_train.py:314-367 / t_est_train.py:285-332: for every reference row i, transfer the whole test batch to
+    ref_labels[i] and average four losses over the B passes.  ``estimator_eval`` is ``self.estimator_`` (raw outputs) in
+    t_cls_train (:338) and ``self.estimator`` in t_est_train (:309).  The scripts never call .eval(): G's dropout and D's
+    power iteration stay active there; this restatement takes the deterministic part (eval-mode G, D buffers frozen).
+    Returns (dict of the four means, list of the B fake batches)."""
+    bs, nc = images.shape[0], ref_labels.shape[1]
+    adv, l1, w, d = [], [], [], []
+    fakes = []
+    with torch.no_grad():
+        for i in range(bs):
+            ref_expand = torch.cat([ref_labels[i]] * bs).view(-1, nc)                   # :336
+            fake = cunet_forward(gp, images, ref_expand)                                # :337
+            fake_c = estimator_eval(fake)                                               # :338
+            real_d = sndisc_forward(dp, images, labels, train=False)[0][0]              # :340
+            fake_d = sndisc_forward(dp, fake, ref_expand, train=False)[0][0]            # :341
+            fakes.append(fake)
+            adv.append(gen_hinge(fake_d).item())                                        # :349
+            l1.append(F.l1_loss(fake, images).item())                                   # :350
+            w.append(pred_loss(fake_c, ref_expand).item())                              # :351
+            d.append(dis_hinge(fake_d, real_d).item())                                  # :352
+    return {"g_loss_adv": float(np.mean(adv)), "g_loss_l1": float(np.mean(l1)), "g_loss_w": float(np.mean(w)),
+            "d_loss": float(np.mean(d))}, fakes

@@ -183,3 +183,182 @@ def test_reducer_single_process_noop():
     assert all(p.grad is not None for p in m.parameters())
     with pytest.raises(ValueError):
         GradBucketReducer([])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# several backward passes per optimizer step (micro-batches): a gradient that reaches a bucket whose all-reduce is already in
+# flight must raise; inside `with reducer.accumulate():` the launches wait for finalize() and the sums are exact
+# ---------------------------------------------------------------------------------------------------------------------------
+def _accum_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "weather-unet_amd"))
+    from wu.ddp import GradBucketReducer, shard_batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = _toy(seed=3)
+        red = GradBucketReducer(list(m.parameters()), bucket_mb=1e-3)
+        torch.manual_seed(77)
+        x, y = torch.randn(16, 6), torch.randn(16, 1)
+        xs, ys = shard_batch(x, rank, world), shard_batch(y, rank, world)
+        halves = [(xs[:4], ys[:4]), (xs[4:], ys[4:])]
+        # (a) unguarded second backward: must raise, not silently race
+        red.zero_grad()
+        torch.mean((m(halves[0][0]) - halves[0][1]) ** 2).backward()
+        raised = False
+        try:
+            torch.mean((m(halves[1][0]) - halves[1][1]) ** 2).backward()
+        except RuntimeError as e:
+            raised = "accumulate" in str(e)
+        red.finalize()
+        # (b) the supported way
+        red.zero_grad()
+        with red.accumulate():
+            for xa, ya in halves:
+                (0.5 * torch.mean((m(xa) - ya) ** 2)).backward()
+            launched_inside = list(red.launch_log)
+        red.finalize()
+        q.put((rank, raised, launched_inside, [p.grad.detach().numpy().copy() for p in m.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_micro_batch_accumulation_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_accum_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import numpy as np
+    for _, raised, launched_inside, _ in res:
+        assert raised, "a gradient arriving after its bucket's all-reduce was launched must raise"
+        assert launched_inside == [], "accumulate(): nothing may be launched before finalize()"
+    for a, b in zip(res[0][3], res[1][3]):
+        assert np.array_equal(a, b)
+    m = _toy(seed=3)
+    torch.manual_seed(77)
+    x, y = torch.randn(16, 6), torch.randn(16, 1)
+    torch.mean((m(x) - y) ** 2).backward()          # == mean over ranks of (0.5 * mse(half 1) + 0.5 * mse(half 2))
+    for g, p in zip(res[0][3], m.parameters()):
+        ref = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert torch.allclose(torch.from_numpy(g), ref, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the fused node's REAL gradient routing (wu.unet_graph.GradRouter) with two producer streams, on recording fake streams:
+# every announcement is made on the side stream after it waited for the main stream, so a bucket's collective (ordered after
+# the stream that is current at the announcement) can never start before a producer on either stream
+# ---------------------------------------------------------------------------------------------------------------------------
+class _FakeStream:
+    def __init__(self, name, log):
+        self.name, self.log = name, log
+
+    def wait_stream(self, other):
+        self.log.append(("wait", self.name, other.name))
+
+
+class _FakeOps:
+    def __init__(self, main):
+        self.cur = [main]
+
+    def current(self):
+        return self.cur[-1]
+
+    def use(self, stream):
+        ops = self
+
+        class _Ctx:
+            def __enter__(self_):
+                ops.cur.append(stream)
+
+            def __exit__(self_, *exc):
+                ops.cur.pop()
+                return False
+        return _Ctx()
+
+
+def _router_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "weather-unet_amd"))
+    from wu.ddp import GradBucketReducer, shard_batch
+    from wu.unet_graph import GradRouter
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(11)
+        # three "layers" (weight, bias): parameter list laid out like UNetFn's P (iw, iw + 1 pairs)
+        P = [torch.nn.Parameter(torch.randn(*shp)) for shp in ((40, 6), (40,), (30, 40), (30,), (1, 30), (1,))]
+        order = [P[4], P[5], P[2], P[3], P[0], P[1]]                     # ready order: last layer first
+        red = GradBucketReducer(order, bucket_mb=1e-4, ready_order=True)  # one parameter per bucket
+        torch.manual_seed(123)
+        x, y = torch.randn(8, 6), torch.randn(8, 1)
+        xs, ys = shard_batch(x, rank, world), shard_batch(y, rank, world)
+        log = []
+        main, side = _FakeStream("main", log), _FakeStream("side", log)
+        ops = _FakeOps(main)
+        announce_stream = []
+        orig = red.grad_written
+
+        def spy(p):
+            announce_stream.append(ops.current().name)
+            log.append(("announce", ops.current().name))
+            orig(p)
+        red.grad_written = spy
+        red.zero_grad()
+        # forward + manual backward of a 3-layer MLP, gradients routed exactly as UNetFn.backward routes them
+        h1 = torch.tanh(xs @ P[0].t() + P[1]); h2 = torch.tanh(h1 @ P[2].t() + P[3]); out = h2 @ P[4].t() + P[5]
+        g = 2 * (out - ys) / out.numel()
+        router = GradRouter(red, P, [tuple(p.shape) for p in P], lambda shp: torch.empty(shp), ops, main, side)
+        with torch.no_grad():
+            # layer 3: a "thin" layer whose gradient kernel runs on the MAIN stream (like conv_last / the first conv)
+            dw, db, acc = router.bufs(4)
+            dw.copy_(g.t() @ h2); db.copy_(g.sum(0)); router.done(("l3", 0), 4, dw, db)
+            g2 = (g @ P[4]) * (1 - h2 * h2)
+            # layers 2, 1: weight-gradient kernels on the SIDE stream
+            for key, iw, gin, inp in (("l2", 2, g2, h1), ("l1", 0, None, xs)):
+                if gin is None:
+                    gin = (g2 @ P[2]) * (1 - h1 * h1)
+                dw, db, acc = router.bufs(iw)
+                router.on_side(lambda: (dw.copy_(gin.t() @ inp), db.copy_(gin.sum(0)), router.done((key, 0), iw, dw, db)))
+        launched = list(red.launch_log)
+        red.finalize()
+        q.put((rank, [p.grad.detach().numpy().copy() for p in P], launched, announce_stream, log, len(red.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fused_node_grad_router_two_streams_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_router_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import numpy as np
+    (_, g0, launched, ann, log, nb), (_, g1, launched1, ann1, _, _) = res
+    for a, b in zip(g0, g1):
+        assert np.array_equal(a, b)
+    assert nb == 6 and launched == list(range(6)) == launched1        # every bucket launched from inside "backward", in ready order
+    assert ann == ["side"] * 6 == ann1                                 # announcements always on the side stream ...
+    for i, ev in enumerate(log):                                       # ... each preceded by side.wait_stream(main)
+        if ev[0] == "announce":
+            before = [e for e in log[:i] if e[0] == "wait"]
+            assert before and before[-1] == ("wait", "side", "main")
+    # == single-process gradient of the full batch
+    torch.manual_seed(11)
+    P = [torch.nn.Parameter(torch.randn(*shp)) for shp in ((40, 6), (40,), (30, 40), (30,), (1, 30), (1,))]
+    torch.manual_seed(123)
+    x, y = torch.randn(8, 6), torch.randn(8, 1)
+    h1 = torch.tanh(x @ P[0].t() + P[1]); h2 = torch.tanh(h1 @ P[2].t() + P[3])
+    torch.mean((h2 @ P[4].t() + P[5] - y) ** 2).backward()
+    for g, p in zip(g0, P):
+        assert torch.allclose(torch.from_numpy(g), p.grad, atol=1e-5), (torch.from_numpy(g) - p.grad).abs().max()

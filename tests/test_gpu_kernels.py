@@ -318,7 +318,7 @@ def test_adain_upcat_bwd_mask_bits_vs_rehash(p):
     bits = torch.zeros(n * 4 * h * w * (c * esz // 16), dtype=torch.uint8, device=_dev())
     s = stream_ptr()
     _lib.call("wu_adain_upcat_fwd", x.data_ptr(), nhwc_ld(x), stats.data_ptr(), ystd.data_ptr(), ymean.data_ptr(),
-              cat.data_ptr(), nhwc_ld(cat), n, h, w, c, 0.3, seed, bits.data_ptr(), code, s)
+              cat.data_ptr(), nhwc_ld(cat), n, h, w, c, 0.3, seed, None, bits.data_ptr(), 0, code, s)
     keep_frac = sum(bin(int(b)).count("1") for b in bits[:4096].cpu().tolist()) / (4096 * (16 // esz))
     assert abs(keep_frac - 0.7) < 0.03
     res = []

@@ -1,0 +1,122 @@
+"""CPU: host logic that needs no GPU -- the ops.py losses / helpers against their reference definitions, the keep-mask
+packing used for injected dropout masks, the content-hash build stamps, bench.py's self-launch of N ranks (gloo rendezvous
+only), the oracle's bf16-emulation mode (sanity: it is the fp32 graph with rounding points), and the batched evaluation()
+identity the product relies on."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cunet_ref as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ops_losses_match_reference_definitions():
+    import ops
+    torch.manual_seed(0)
+    fake, real = torch.randn(6, 1), torch.randn(6, 1)
+    assert torch.equal(ops.dis_hinge(fake, real), torch.mean(torch.relu(1. - real)) + torch.mean(torch.relu(1. + fake)))   # ops.py:42-45
+    assert torch.equal(ops.gen_hinge(fake), torch.mean(-fake))                                                             # ops.py:47-48
+    a, b = torch.randn(4, 3, 8, 8), torch.randn(4, 3, 8, 8)
+    assert torch.equal(ops.l1_loss(a, b), F.l1_loss(a, b)) and torch.equal(ops.adv_loss(a, b), F.mse_loss(a, b))
+    with pytest.raises(AssertionError):
+        ops.l1_loss(a, b[:2])
+    logits, soft, idx = torch.randn(5, 5), torch.softmax(torch.randn(5, 5), 1), torch.tensor([0, 3, 2, 4, 1])
+    assert torch.equal(ops.pred_loss(logits, soft), torch.nn.MSELoss()(logits, soft))                                      # ops.py:37-39
+    assert torch.equal(ops.pred_loss(logits, idx, one_hot=True), torch.nn.CrossEntropyLoss()(logits, idx))                 # ops.py:30-36
+    maps_a, maps_b = [torch.randn(2, 4, 4, 4), torch.randn(2, 8, 2, 2)], [torch.randn(2, 4, 4, 4), torch.randn(2, 8, 2, 2)]
+    assert torch.allclose(ops.feat_loss(maps_a, maps_b), torch.mean(torch.stack([F.l1_loss(u, v) for u, v in zip(maps_a, maps_b)])))
+    v = torch.tensor([[0.1, 0.9], [0.7, 0.2], [0.2, 0.3]])
+    ref = torch.zeros_like(v).scatter_(0, torch.argmax(v, 0, keepdim=True), 1)                                            # ops.py:50-54
+    assert torch.equal(ops.vector_to_one_hot(v), ref)
+    assert torch.equal(ops.make_table_img(a, None, [b, a]), torch.cat([a, b, a], dim=2))
+    # `from ops import *` must leak the names the scripts rely on (t_cls_train.py:328 uses F)
+    ns = {}
+    exec("from ops import *", ns)
+    for name in ("F", "Variable", "np", "nn", "torch", "gen_hinge", "dis_hinge", "l1_loss", "adv_loss", "pred_loss",
+                 "get_rand_labels", "get_sequential_labels", "Variable_Float", "make_table_img", "soft_transform"):
+        assert name in ns, name
+
+
+def test_pack_keep_mask_layout():
+    from wu.kernels import pack_keep_mask
+    g = torch.Generator().manual_seed(5)
+    for dtype, e in ((torch.bfloat16, 8), (torch.float32, 4)):
+        m = (torch.rand((2, 16, 3, 5), generator=g) < 0.7).to(torch.uint8)
+        bits = pack_keep_mask(m, dtype).numpy()
+        n, c, h, w = m.shape
+        assert bits.shape == (n * h * w * c // e,)
+        for (ni, hi, wi, ch) in ((0, 0, 0, 0), (1, 2, 4, 1), (0, 1, 3, c // e - 1)):
+            byte = bits[((ni * h + hi) * w + wi) * (c // e) + ch]
+            for k in range(e):
+                assert (byte >> k) & 1 == int(m[ni, ch * e + k, hi, wi])
+
+
+def test_build_stamp_is_content_hash(tmp_path, monkeypatch):
+    from wu import _build
+    if _build.is_stale():
+        _build.build(verbose=False)
+    assert not _build.is_stale()
+    h0 = _build.source_hash()
+    # a changed source byte -> stale, regardless of mtimes
+    real = _build.sources
+    fake_src = tmp_path / "extra.hip"
+    fake_src.write_text("// new kernel\n")
+    monkeypatch.setattr(_build, "sources", lambda: real() + [str(fake_src)])
+    assert _build.source_hash() != h0 and _build.is_stale()
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts its own ranks (child processes through the stock launcher)
+    and rank 0 prints ONE JSON line; --launch-check keeps it to the rendezvous (gloo), so it runs without a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"launch_check": 2, "n_gpus": 2}
+
+
+def test_oracle_bf16_emulation_is_the_same_graph_with_rounding_points():
+    nc, seed = 5, 2
+    p = {k: v.clone().requires_grad_(True) for k, v in O.make_cunet_params(nc, seed).items()}
+    x, c = O.make_inputs(1, 32, nc, seed, True)
+    y32 = O.cunet_forward(p, x, c)
+    y16, st = O.cunet_forward(p, x, c, emulate_bf16=True, return_stages=True)
+    assert 0 < (y32 - y16).abs().max().item() <= 5e-2            # a bf16-sized perturbation, not a different function
+    for k in ("conv1", "conv2", "conv3", "bottleneck", "up3", "up2", "up1"):
+        t = st[k].detach()
+        assert torch.equal(t, t.to(torch.bfloat16).float()), k    # every parked tensor is exactly representable in bf16
+    O.bench_loss(y16, x).backward()
+    g = p["dconv_down2.0.weight"].grad
+    assert g is not None and g.dtype == torch.float32 and not torch.equal(g, g.to(torch.bfloat16).float())   # dW stays fp32
+
+
+def test_batched_evaluation_identity():
+    """evaluation() (t_cls_train.py:314-367) averages per-pass means over B passes; one pass over the B*B (image, condition)
+    pairs gives the same four numbers because every pass has the same size -- the identity the product's batched
+    evaluation() (wu/train_step.py) relies on.  Checked on the oracle restatement itself."""
+    nc, seed, bs = 5, 4, 3
+    gp, dp = O.make_cunet_params(nc, seed), O.make_sndisc_params(nc, seed)
+    images, labels = O.make_inputs(bs, 32, nc, seed, True)
+    _, ref_labels = O.make_inputs(bs, 32, nc, seed + 1, True)
+    lin = torch.nn.Linear(3 * 32 * 32, nc)
+    est = lambda t: lin(t.flatten(1))
+    looped, fakes = O.evaluation(gp, dp, est, est, images, labels, ref_labels)
+    with torch.no_grad():
+        cond = ref_labels.repeat_interleave(bs, dim=0)
+        xx = images.repeat(bs, 1, 1, 1)
+        fake = O.cunet_forward(gp, xx, cond)
+        fd = O.sndisc_forward(dp, fake, cond, train=False)[0][0]
+        rd = O.sndisc_forward(dp, images, labels, train=False)[0][0]
+        batched = {"g_loss_adv": O.gen_hinge(fd).item(), "g_loss_l1": F.l1_loss(fake, xx).item(),
+                   "g_loss_w": F.mse_loss(est(fake), cond).item(), "d_loss": O.dis_hinge(fd, rd).item()}
+    assert torch.allclose(fake.view(bs, bs, 3, 32, 32), torch.stack(fakes), atol=1e-5)
+    for k in looped:
+        assert abs(looped[k] - batched[k]) <= 1e-5 * max(1.0, abs(looped[k])), (k, looped[k], batched[k])

@@ -456,7 +456,8 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     if (ntiles >= (1ll << 31)) return -1;
     a.ntiles = (int)ntiles;
     // persistent: one 8-wave workgroup per CU; each walks a contiguous tile range and prefetches across tiles
-    const long long grid = (ntiles < 256 || !g_wu_opt[WU_OPT_CONV_PERSISTENT]) ? ntiles : 256;
+    const int cus = wu_num_cus();
+    const long long grid = (ntiles < cus || !g_wu_opt[WU_OPT_CONV_PERSISTENT]) ? ntiles : cus;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -355,7 +355,7 @@ WgradV2Plan wgrad_v2_plan(int N, int H, int W, int Cin, int Cout) {
     p.ntiles = N * p.tiles_x * p.tiles_y;
     p.co_blocks = Cout / 64; p.ci_blocks = Cin / 64;
     const int blocks = p.co_blocks * p.ci_blocks;
-    int splits = 256 / blocks;                      // one 512-thread workgroup per CU, one wave of workgroups
+    int splits = wu_num_cus() / blocks;             // one 512-thread workgroup per CU, one wave of workgroups
     if (splits < 1) splits = 1;
     if (splits > p.ntiles) splits = p.ntiles;
     p.tiles_per_split = cdiv(p.ntiles, splits);

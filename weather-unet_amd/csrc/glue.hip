@@ -210,11 +210,13 @@ __global__ __launch_bounds__(256) void adain_upcat_fwd_kernel(const T* __restric
                                        const float* __restrict__ y_std, const float* __restrict__ y_mean,
                                        T* __restrict__ y, int ldy, int N, int H, int W, int C,
                                        float sy, float sx, uint32_t thr, float keep_scale, uint64_t seed,
-                                       uint8_t* __restrict__ mbits) {
+                                       const uint64_t* __restrict__ seed_dev, uint8_t* __restrict__ mbits, int mask_in) {
     constexpr int E = ElemTraits<T>::kPer16B;
     const int cpp = C / E, H2 = 2 * H, W2 = 2 * W;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= W2 * cpp) return;
+    // graph-safe per-replay seed: the captured kernel argument is frozen, the device-resident counter is not
+    if (seed_dev) seed += *seed_dev;
     const int ow = idx / cpp, ch = idx - ow * cpp;
     const Lerp lx = src_index(ow, sx, W);
     constexpr int RPT = 4;                           // consecutive output rows per thread (same image)
@@ -257,7 +259,11 @@ __global__ __launch_bounds__(256) void adain_upcat_fwd_kernel(const T* __restric
                 unpack16<T>(q[r][3], v11);
                 const size_t opix = ((size_t)n * H2 + oh) * W2 + ow;
                 bool keep[E];
-                if (thr < 0x10000u) {
+                if (thr < 0x10000u && mask_in) {       // caller-supplied keep bits (a mask captured from the reference)
+                    const uint32_t bits = mbits[opix * cpp + ch];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) keep[e] = (bits >> e) & 1u;
+                } else if (thr < 0x10000u) {
                     keep_bits<E>(seed, (uint64_t)opix * C + ch * E, thr, keep);
                     if (mbits) {        // one byte per 16-B chunk: backward reads the mask instead of re-hashing
                         uint32_t bits = 0;
@@ -628,18 +634,19 @@ extern "C" int wu_adain_stats(const void* x, int ldx, float* stats, float* scrat
 
 extern "C" int wu_adain_upcat_fwd(const void* x, int ldx, const float* stats, const float* y_std, const float* y_mean,
                                   void* y, int ldy, int N, int H, int W, int C, float p_drop, uint64_t seed,
-                                  uint8_t* mask_bits, int dtype, void* stream) {
+                                  const uint64_t* seed_dev, uint8_t* mask_bits, int mask_is_input, int dtype, void* stream) {
     const int esz = dtype == WU_BF16 ? 2 : 4;
     WU_REQUIRE(C % (16 / esz) == 0 && C <= ldx && C <= ldy && H > 1 && W > 1, "adain_upcat_fwd: bad shape");
     WU_REQUIRE(ok16(x, ldx, esz) && ok16(y, ldy, esz), "adain_upcat_fwd: alignment");
     WU_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "adain_upcat_fwd: p_drop");
+    WU_REQUIRE(!mask_is_input || mask_bits, "adain_upcat_fwd: mask_is_input without mask_bits");
     const float sy = (float)(H - 1) / (float)(2 * H - 1), sx = (float)(W - 1) / (float)(2 * W - 1);
     WU_REQUIRE(((uintptr_t)stats % 16) == 0 && ((uintptr_t)y_std % 16) == 0 && ((uintptr_t)y_mean % 16) == 0, "adain_upcat_fwd: stats alignment");
     const int rows = N * cdiv(2 * H, 4);            // 4 output rows per thread
     const dim3 grid(cdiv(2 * W * (C / (16 / esz)), 256), rows < 32768 ? rows : 32768);
     DISPATCH_T(dtype, hipLaunchKernelGGL(adain_upcat_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
                                          (const T*)x, ldx, stats, y_std, y_mean, (T*)y, ldy, N, H, W, C, sy, sx,
-                                         keep_thr(p_drop), 1.f / (1.f - p_drop), seed, mask_bits));
+                                         keep_thr(p_drop), 1.f / (1.f - p_drop), seed, seed_dev, mask_bits, mask_is_input));
     WU_LAUNCH_CHECK("adain_upcat_fwd");
     return 0;
 }

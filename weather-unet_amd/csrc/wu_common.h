@@ -42,6 +42,8 @@ extern void* g_wu_dbg_ptr;
 #define WU_OPT_CONV_PRIO 6
 #define WU_OPT_CONV_STRIDED 7
 
+int wu_num_cus();   // compute units of the current device (wu_prof.hip), cached
+
 // ---- profiling hooks (wu_prof.hip) --------------------------------------------------------------
 void wu_prof_pre(int family, hipStream_t s);
 void wu_prof_post(int family, hipStream_t s, double flops, double bytes);

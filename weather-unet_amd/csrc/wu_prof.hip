@@ -6,7 +6,20 @@
 thread_local char g_wu_err[256] = {0};
 
 extern "C" const char* wu_last_error(void) { return g_wu_err; }
-extern "C" int wu_version(void) { return 1; }
+extern "C" int wu_version(void) { return 2; }
+
+// Compute units of the current device, read once (the persistent conv / weight-gradient grids launch one workgroup per CU).
+// Without a usable device (the CPU-only build container: workspace sizing in the ABI tests) the MI355X figure is assumed.
+int wu_num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else { (void)hipGetLastError(); cus = 256; }
+    }
+    return cus;
+}
+extern "C" int wu_cu_count(void) { return wu_num_cus(); }
 
 // tuning switches (A/B benchmarking of kernel variants inside one process; defaults are the production choices)
 int g_wu_opt[16] = {/*CONV_V2*/ 1, /*CONV_PERSISTENT*/ 1, /*WGRAD_V2*/ 1, /*CONV_CT_SLOWEST*/ 0, /*WGRAD_DMA_INTERLEAVE*/ 1, /*C3_ROWS*/ 0, /*CONV_PRIO*/ 1, /*CONV_STRIDED*/ 1, 0, 0, 0, 0, 0, 0, 0, 0};

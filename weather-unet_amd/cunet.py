@@ -31,13 +31,14 @@ class Conditional_UNet(nn.Module):
 
     def init_weight(self, std=0.2):
         """reference cunet.py:9-16 (defined, never called there: :41 is commented out)."""
-        for m in self.modules():
-            cn = m.__class__.__name__
-            if cn.find('Conv') != -1 and hasattr(m, 'weight') and isinstance(m.weight, nn.Parameter):
-                m.weight.data.normal_(0., std)
-            elif cn.find('Linear') != -1:
-                m.weight.data.normal_(1., std)
-                m.bias.data.fill_(0)
+        with torch.no_grad():      # in place on the parameters themselves (not .data): bumps ._version -> packed operands follow
+            for m in self.modules():
+                cn = m.__class__.__name__
+                if cn.find('Conv') != -1 and hasattr(m, 'weight') and isinstance(m.weight, nn.Parameter):
+                    m.weight.normal_(0., std)
+                elif cn.find('Linear') != -1:
+                    m.weight.normal_(1., std)
+                    m.bias.fill_(0)
 
     def __init__(self, num_classes, precision="bf16"):
         super(Conditional_UNet, self).__init__()
@@ -64,6 +65,8 @@ class Conditional_UNet(nn.Module):
         self.activation = nn.Tanh()
         self.set_precision(precision)
         self.dropout_seed = None     # int -> reproducible dropout masks (tests); None -> fresh seed per call
+        self.dropout_masks = None    # (m3, m2, m1) NCHW keep-masks for cunet.py:61,68,75: used INSTEAD of the counter RNG
+        self._seed_dev = None        # int64 device scalar added to the seeds inside the kernels (wu.graph_infer: per-replay masks)
         self.fused = True            # one autograd node for the whole net (wu/unet_graph.py); False = per-layer Functions
         self.grad_sink = None        # wu.ddp.GradBucketReducer.attach(): overlap gradient all-reduce with the fused backward
 
@@ -88,7 +91,11 @@ class Conditional_UNet(nn.Module):
         """cunet.py:59-62 / 66-69 / 73-76 as one fused op."""
         y_std, y_mean = adain.style(c)
         p = self.dropout.p if self.training else 0.0
-        return WF.adain_upcat(x, y_std, y_mean, skip, catbuf, adain.eps, p, self._next_seed(k))
+        mask_in = None
+        if p > 0 and self.dropout_masks is not None:
+            from wu.kernels import pack_keep_mask
+            mask_in = pack_keep_mask(self.dropout_masks[3 - k].to(x.device), x.dtype)
+        return WF.adain_upcat(x, y_std, y_mean, skip, catbuf, adain.eps, p, self._next_seed(k), self._seed_dev, mask_in)
 
     def forward(self, x, c):
         require_cuda(x, "Conditional_UNet")

@@ -45,6 +45,11 @@ class _Conv3x3Base(nn.Module):
     def effective_weight(self):
         raise NotImplementedError
 
+    def weight_ident(self):
+        """Identity of what effective_weight() was computed from, for the packed-operand cache (None: the weight tensor's own
+        storage pointer + version is the identity)."""
+        return None
+
     def forward(self, x, act=None, out=None, out_nchw=False):
         require_cuda(x, type(self).__name__)
         act = self.act if act is None else act
@@ -53,7 +58,7 @@ class _Conv3x3Base(nn.Module):
         if self.in_channels == 3:
             return WF.conv3x3_c3(x, w, self.bias, self.stride, act, out_nchw, code)
         x = WF.to_nhwc(x, code)
-        return WF.conv3x3(x, w, self.bias, self._packed, self.stride, act, out)
+        return WF.conv3x3(x, w, self.bias, self._packed, self.stride, act, out, self.weight_ident())
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, kernel_size=(3, 3), stride={self.stride}, padding=(1, 1)"
@@ -89,6 +94,7 @@ class SNConv3x3(_Conv3x3Base):
             v = F_.normalize(w.new_empty(in_channels * 9).normal_(0, 1), dim=0, eps=eps)
         self.register_buffer("weight_u", u)
         self.register_buffer("weight_v", v)
+        self._sn_generation = 0        # bumped whenever a power iteration rewrites weight_u / weight_v through raw pointers
 
     @property
     def weight(self):
@@ -96,7 +102,16 @@ class SNConv3x3(_Conv3x3Base):
         return spectral_normalize(self.weight_orig, self.weight_u, self.weight_v, False, self.eps)
 
     def effective_weight(self):
+        if self.training:
+            self._sn_generation += 1
         return spectral_normalize(self.weight_orig, self.weight_u, self.weight_v, self.training, self.eps)
+
+    def weight_ident(self):
+        # W/sigma is a fresh temporary per forward (its pointer repeats from step to step): key the packed operands on what it
+        # was computed from -- weight_orig (optimizer steps bump its version), the power-iteration buffers (load_state_dict
+        # bumps theirs; the HIP power iteration writes them through raw pointers, hence the explicit generation)
+        return (self.weight_orig.data_ptr(), self.weight_orig._version, self.weight_u.data_ptr(), self.weight_u._version,
+                self.weight_v._version, self._sn_generation)
 
 
 def spectral_normalize(weight_orig, u, v, do_power_iteration, eps=1e-12):

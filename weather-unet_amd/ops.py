@@ -1,86 +1,95 @@
-"""Losses and label helpers -- same names and behaviour as the reference's ops.py (ops.py:14-83).
+"""Losses and label helpers behind the reference's ``ops`` module name (reference ops.py:14-83).
 
-These are tiny reductions on (N,1) / (N,nc) / (N,3,H,W) tensors: they stay torch ops in fp32
-(SURVEY.md 8a12).  ``from ops import *`` also leaks ``F``, ``Variable``, ``np``, ``nn``, ``torch`` exactly
-as the reference's does (t_cls_train.py:328 relies on ``F``)."""
-import os  # noqa: F401
-
+The five loss one-liners sit inside the GAN step: tiny reductions on (N,1) / (N,nc) / (N,3,H,W) tensors
+that stay fp32 torch ops.  The label / image helpers are host-side conveniences (off the hot path); they keep
+the reference's names and call signatures because its scripts reach them through ``from ops import *``, which also leaks
+``F``, ``Variable``, ``np``, ``nn``, ``torch`` (t_cls_train.py:328 uses ``F`` obtained that way) -- hence ``__all__`` below.
+"""
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.autograd import Variable
-import numpy as np
 
 xp = np
 
+__all__ = ["F", "Variable", "np", "nn", "torch", "xp",
+           "adv_loss", "l1_loss", "feat_loss", "pred_loss", "dis_hinge", "gen_hinge",
+           "soft_transform", "vector_to_one_hot", "get_rand_labels", "get_sequential_labels", "Variable_Float", "make_table_img"]
 
-def soft_transform(x, std=0.05):
-    dist = torch.zeros_like(x).normal_(0, std=std)
-    return x + dist
 
-
-def adv_loss(a, b):
+def _same_size(a, b):
     assert a.size() == b.size(), 'The size of a and b is different.{}!={}'.format(a.size(), b.size())
+
+
+# ---- losses used inside the step (t_cls_train.py:254-270,305; t_est_train.py:232-243,274) -----------------------------------
+def adv_loss(a, b):
+    """ops.py:18-20: mean squared error between two same-sized tensors."""
+    _same_size(a, b)
     return F.mse_loss(a, b)
 
 
 def l1_loss(a, b):
-    assert a.size() == b.size(), 'The size of a and b is different.{}!={}'.format(a.size(), b.size())
+    """ops.py:22-24: mean absolute error (logged as g_loss_l1, not part of g_loss)."""
+    _same_size(a, b)
     return F.l1_loss(a, b)
 
 
 def feat_loss(a, b):
-    return torch.mean(torch.stack([F.l1_loss(a_.float(), b_.float()) for a_, b_ in zip(a, b)]))
+    """ops.py:26-27: mean over feature-map pairs of their L1 distance (SNDisc's c1..c4 arrive in the compute dtype: fp32 here)."""
+    per_map = [F.l1_loss(u.float(), v.float()) for u, v in zip(a, b)]
+    return torch.stack(per_map).mean()
 
 
 def pred_loss(preds, labels, one_hot=False):
-    if one_hot:
-        criterion = nn.CrossEntropyLoss()
-    else:
-        criterion = nn.MSELoss()
-    return criterion(preds, labels)
+    """ops.py:29-40: weather-prediction loss -- cross entropy on un-softmaxed logits vs class indices (``--cross_ent``),
+    else MSE against the (soft) label rows."""
+    return F.cross_entropy(preds, labels) if one_hot else F.mse_loss(preds, labels)
 
 
 def dis_hinge(dis_fake, dis_real):
-    loss = torch.mean(torch.relu(1. - dis_real)) + \
-        torch.mean(torch.relu(1. + dis_fake))
-    return loss
+    """ops.py:42-45: hinge loss of the discriminator."""
+    return F.relu(1. - dis_real).mean() + F.relu(1. + dis_fake).mean()
 
 
 def gen_hinge(dis_fake):
-    return torch.mean(-dis_fake)
+    """ops.py:47-48: hinge loss of the generator."""
+    return (-dis_fake).mean()
+
+
+# ---- host-side helpers (off the hot path; names kept for `from ops import *`) -----------------------------------------------
+def soft_transform(x, std=0.05):
+    """Label smoothing by additive Gaussian noise (ops.py:14-16)."""
+    return x + std * torch.randn_like(x)
 
 
 def vector_to_one_hot(vec):
-    arg = torch.argmax(vec, 0, keepdim=True)
-    one_hot = torch.zeros_like(vec)
-    one_hot.scatter_(0, arg, 1).float()
-    return one_hot
+    """One-hot of the arg-max along dim 0, same shape / dtype as `vec` (ops.py:50-54)."""
+    idx = vec.argmax(dim=0)
+    return torch.movedim(F.one_hot(idx, vec.shape[0]), -1, 0).to(vec.dtype)
 
 
 def get_rand_labels(num_classes, batch_size, one_hot=False):
-    label = torch.FloatTensor(batch_size, num_classes).uniform_(-1, 1)
+    """Random conditioning rows on the GPU (ops.py:56-60): U(-1, 1) signal rows, or -- with one_hot -- one-hot rows of uniformly
+    drawn classes (the reference passes its float tensor to F.one_hot there, which raises; never called with one_hot=True)."""
     if one_hot:
-        label = F.one_hot(label, num_classes)
-    return label.to('cuda')
+        cls = torch.randint(num_classes, (batch_size,))
+        return F.one_hot(cls, num_classes).float().to('cuda')
+    return (torch.rand(batch_size, num_classes) * 2 - 1).to('cuda')
 
 
 def get_sequential_labels(num_classes, batch_size, one_hot=False):
-    rep = batch_size // num_classes + 1
-    if one_hot:
-        arr = xp.eye(num_classes, dtype=xp.float32)
-        arr = xp.tile(arr, (rep, 1))[:batch_size]
-        return torch.from_numpy(arr).float().to('cuda')
-    else:
-        arr = torch.arange(num_classes, dtype=torch.float32)
-        arr = arr.repeat(rep)[:batch_size]
-        return arr.to('cuda')
+    """Classes 0, 1, .., nc-1, 0, 1, .. for a batch (ops.py:62-71): float class ids, or their one-hot rows."""
+    cls = torch.arange(batch_size) % num_classes
+    out = torch.eye(num_classes)[cls] if one_hot else cls.float()
+    return out.to('cuda')
 
 
 def Variable_Float(x, batch_size):
-    return Variable(torch.full((batch_size, 1), float(x), device='cuda'), requires_grad=False)
+    """(batch_size, 1) constant on the GPU (ops.py:73-74; the real / fake targets of t_cls_train.py:77-78)."""
+    return torch.full((batch_size, 1), float(x), device='cuda', requires_grad=False)
 
 
 def make_table_img(images, ref_images, results):
-    in_out_img = torch.cat([images] + results, dim=2)
-    return in_out_img
+    """Input batch and its transfers stacked along the height axis (ops.py:77-83; `ref_images` is unused there too)."""
+    return torch.cat([images, *results], dim=2)

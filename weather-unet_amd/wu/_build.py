@@ -4,6 +4,7 @@
 
 The .so is kept in-tree (weather-unet_amd/lib/, git-ignored) so it travels with the repo snapshot.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -21,8 +22,37 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _newer(a, b):
-    return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
+STAMP = os.path.join(LIBDIR, "source_hash.txt")
+
+
+def _headers():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(INCLUDE, "wu_kernels.h")]
+
+
+def source_hash(src=None):
+    """sha256 over the compile flags, every header and `src` (or all sources): what an object / the library was built FROM.
+    Content, not mtimes: a checkout, a copy to another box or a touched file cannot make a stale object look fresh."""
+    h = hashlib.sha256(" ".join(FLAGS[:5]).encode())
+    for f in _headers() + ([src] if src else sources()):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _stamps():
+    out = {}
+    if os.path.exists(STAMP):
+        for line in open(STAMP):
+            k, _, v = line.strip().partition(" ")
+            if v:
+                out[k] = v
+    return out
+
+
+def is_stale():
+    """True if libwu_kernels.so is missing or was not built from the sources in the tree."""
+    return not os.path.exists(LIB) or _stamps().get("libwu_kernels.so") != source_hash()
 
 
 def build(force=False, verbose=True):
@@ -30,12 +60,14 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "wu_kernels.h")]
-    objs, jobs = [], []
+    stamps = _stamps()
+    objs, jobs, new = [], [], {}
     for src in sources():
-        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+        name = os.path.basename(src)[:-4] + ".o"
+        obj = os.path.join(LIBDIR, name)
         objs.append(obj)
-        if force or _newer(src, obj) or any(_newer(h, obj) for h in headers):
+        new[name] = source_hash(src)
+        if force or not os.path.exists(obj) or stamps.get(name) != new[name]:
             jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
 
     def run(cmd):
@@ -45,8 +77,12 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB):
+    new["libwu_kernels.so"] = source_hash()
+    if jobs or not os.path.exists(LIB) or stamps.get("libwu_kernels.so") != new["libwu_kernels.so"]:
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    with open(STAMP, "w") as fh:
+        for k in sorted(new):
+            fh.write(f"{k} {new[k]}\n")
     return LIB
 
 

@@ -26,6 +26,7 @@ P, I, F, U64, SZ = c_void_p, c_int, c_float, c_uint64, c_size_t
 SIGNATURES = {
     "wu_last_error": (c_char_p, []),
     "wu_version": (I, []),
+    "wu_cu_count": (I, []),
     "wu_set_option": (I, [I, I]),
     "wu_set_debug_buffer": (I, [P]),
     "wu_spectral_norm_scratch_floats": (SZ, [I, I]),
@@ -50,7 +51,7 @@ SIGNATURES = {
     "wu_adain_style_fwd": (I, [P, P, P, F, P, P, P, I, I, I, P]),
     "wu_adain_style_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "wu_adain_stats": (I, [P, I, P, P, I, I, I, I, F, I, P]),
-    "wu_adain_upcat_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, F, U64, P, I, P]),
+    "wu_adain_upcat_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, F, U64, P, P, I, I, P]),
     "wu_adain_upcat_bwd": (I, [P, I, P, I, P, P, P, I, P, P, P, P, I, I, I, I, F, U64, P, I, I, P]),
     "wu_dropout_mask": (I, [P, I, I, I, I, F, U64, P]),
     "wu_sumpool_fwd": (I, [P, I, P, I, I, I, I, I, P]),
@@ -77,6 +78,7 @@ def load():
         # loader binds this library to the HIP runtime instance torch initialises -- two runtime copies in
         # one process do not share devices, streams or allocations.
         import torch  # noqa: F401
+        _check_not_stale()
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
@@ -84,6 +86,20 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def _check_not_stale():
+    """A library built from other sources than the ones in the tree must never run silently: compare the content hash the
+    build recorded with the tree's (skipped when the sources did not travel with the library)."""
+    from . import _build
+    if not os.path.isdir(_build.CSRC):
+        return
+    if _build.is_stale():
+        if os.environ.get("WU_ALLOW_STALE_LIB"):
+            return
+        raise RuntimeError(f"{LIB_PATH} was not built from the sources in {_build.CSRC} (content hash mismatch): "
+                           "run `python weather-unet_amd/wu/_build.py` (or __graft_entry__.build()); "
+                           "WU_ALLOW_STALE_LIB=1 overrides")
 
 
 def check(rc, what):

@@ -33,6 +33,10 @@ class GradBucketReducer:
     ``grad_written`` -- a full bucket's all-reduce then runs beside the REST of the backward pass.
 
     Usage per step:  ``reducer.zero_grad(); loss.backward(); reducer.finalize(); optimizer.step()``.
+    Several backward passes per optimizer step (micro-batch accumulation, a network used twice in one graph):
+    ``with reducer.accumulate(): ...backward passes...`` defers every collective to ``finalize()``; without it a gradient
+    that reaches a bucket whose all-reduce has already been launched raises (it would race with the collective and
+    never be reduced).
     ``param.grad`` is a view into its bucket's flat buffer for the lifetime of the reducer (do not call
     ``optimizer.zero_grad(set_to_none=True)``; use ``reducer.zero_grad()``).
     """
@@ -66,8 +70,10 @@ class GradBucketReducer:
         backend = dist.get_backend(group) if dist.is_initialized() else None
         self._avg_op = backend == "nccl"       # RCCL has a native AVG; gloo needs SUM + scale
         self._written = set()                  # parameters whose gradient was written since zero_grad()
+        self._direct = set()                   # ... of those, the ones announced through grad_written() (direct bucket writes)
         self.launch_log = []                   # bucket indices in launch order (tests / tracing)
         self.enabled = True                    # False: gradients deposited by a backward are ignored (not reduced)
+        self.defer = False                     # True (accumulate()): no launch before finalize()
         if broadcast and self.world > 1:
             self.broadcast_parameters()
 
@@ -83,9 +89,11 @@ class GradBucketReducer:
 
     def broadcast_parameters(self, src=0):
         """Replicas start identical (weights and, for SNDisc, the power-iteration buffers via the module's
-        own broadcast_buffers call)."""
-        for p in self.params:
-            dist.broadcast(p.data, src=src, group=self.group)
+        own broadcast_buffers call).  In place on the parameter itself under no_grad -- NOT on ``p.data``, whose writes do
+        not bump ``p._version``: the packed MFMA operand cache (wu.functional.PackedConv) keys on that version."""
+        with torch.no_grad():
+            for p in self.params:
+                dist.broadcast(p, src=src, group=self.group)
 
     def zero_grad(self):
         for b in self.buckets:
@@ -95,6 +103,7 @@ class GradBucketReducer:
             b["launched"] = False
         self.launch_log.clear()
         self._written.clear()
+        self._direct.clear()
 
     def fresh(self, p):
         """True until a gradient of `p` has been written since zero_grad(): the first writer may OVERWRITE the (zeroed) bucket
@@ -113,7 +122,13 @@ class GradBucketReducer:
             # stream, then the collective runs beside the rest of backward
             b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
 
-    def _on_grad_ready(self, p):
+    def _on_grad_ready(self, p, direct=False):
+        if direct:
+            self._direct.add(p)
+        elif p in self._direct:
+            # autograd runs a parameter's post-accumulate hooks even when the node returned None for it (torch >= 2.x): for a
+            # parameter whose gradient the fused node already wrote and announced itself this is not a second gradient
+            return
         self._written.add(p)               # any arrival (autograd hook or direct write): later writers must accumulate
         if not self.enabled:
             return
@@ -122,14 +137,33 @@ class GradBucketReducer:
         if p.grad.data_ptr() < b["flat"].data_ptr() or p.grad.data_ptr() >= b["flat"].data_ptr() + b["flat"].numel() * 4:
             raise RuntimeError("GradBucketReducer: a parameter's .grad was replaced (use reducer.zero_grad(), "
                                "not zero_grad(set_to_none=True))")
+        if b["launched"] and self.world > 1:
+            raise RuntimeError("GradBucketReducer: a gradient arrived for a bucket whose all-reduce is already in flight "
+                               "(second backward / micro-batch without zero_grad()): wrap the backward passes in "
+                               "`with reducer.accumulate():` so the collectives wait for finalize()")
         b["pending"] -= 1
-        if b["pending"] == 0:
+        if b["pending"] == 0 and not self.defer:
             self._launch(bi)
 
     def grad_written(self, p):
         """A producer accumulated this step's gradient of `p` straight into ``p.grad`` (the bucket view) on the current
         stream and returns None for it to autograd: same bookkeeping as the autograd hook."""
-        self._on_grad_ready(p)
+        self._on_grad_ready(p, direct=True)
+
+    def accumulate(self):
+        """Context manager: gradients of several backward passes are summed in the buckets, nothing is launched until
+        ``finalize()`` (called after the block)."""
+        red = self
+
+        class _Defer:
+            def __enter__(self_):
+                red.defer = True
+                return red
+
+            def __exit__(self_, *exc):
+                red.defer = False
+                return False
+        return _Defer()
 
     def owns(self, params):
         return all(p in self._bucket_of for p in params)
@@ -177,8 +211,9 @@ def broadcast_buffers(module, src=0, group=None):
     """Keep SN ``weight_u`` / ``weight_v`` (nets.py:28-31) identical across ranks."""
     if not is_distributed():
         return
-    for b in module.buffers():
-        dist.broadcast(b.data, src=src, group=group)
+    with torch.no_grad():
+        for b in module.buffers():
+            dist.broadcast(b, src=src, group=group)     # on the buffer itself: bumps its version (PackedConv identity)
 
 
 def shard_batch(batch, rank, world):

@@ -26,15 +26,22 @@ def _grad_nhwc(g, code):
 # ----------------------------------------------------------------------------------------------
 class PackedConv:
     """[tap][Cout][Cin] (forward) and [tap'][Cin][Cout] (data-gradient) MFMA operand images of one
-    OIHW fp32 weight, cached on (storage, version, dtype) so a weight is repacked once per update."""
+    OIHW fp32 weight, cached on (storage, version, dtype) so a weight is repacked once per update.
+
+    ``ident``: when `weight` is a TEMPORARY derived from a parameter (the spectral-norm W/sigma of nets.SNConv3x3, a fresh
+    tensor per forward whose storage the caching allocator hands out again at the same point of the next iteration), its
+    pointer / version say nothing about its contents: the owner then passes an explicit identity of what the temporary was
+    computed from (parameter storage + version, buffer versions, power-iteration generation) and that is the key."""
 
     def __init__(self):
         self.key = None
         self.w_fwd = None
         self.w_dgrad = None
 
-    def get(self, weight, code):
-        key = (weight.data_ptr(), weight._version, code, tuple(weight.shape))
+    def get(self, weight, code, ident=None):
+        if ident is None:
+            ident = (weight.data_ptr(), weight._version)
+        key = (ident, code, tuple(weight.shape))
         if key != self.key:
             self.w_fwd, self.w_dgrad = K.pack_conv3x3(weight, code)
             self.key = key
@@ -46,13 +53,13 @@ class PackedConv:
 # ----------------------------------------------------------------------------------------------
 class Conv3x3Fn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, stride, act, out):
+    def forward(ctx, x, weight, bias, packed, stride, act, out, ident=None):
         require_cuda(x, "conv3x3")
         code = dtype_code(x)
         n, cin, h, w = x.shape
         cout = weight.shape[0]
         ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
-        w_fwd, w_dgrad = packed.get(weight, code)
+        w_fwd, w_dgrad = packed.get(weight, code, ident)
         if out is None:
             y = empty_nhwc(n, cout, ho, wo, x.dtype, x.device)
         else:
@@ -87,11 +94,11 @@ class Conv3x3Fn(Function):
             dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
             db = torch.empty((cout,), dtype=torch.float32, device=x.device) if has_bias else None
             K.conv3x3_wgrad(x, gy, dw, db, stride)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv3x3(x, weight, bias, packed, stride=1, act=ACT_NONE, out=None):
-    return Conv3x3Fn.apply(x, weight, bias, packed, stride, act, out)
+def conv3x3(x, weight, bias, packed, stride=1, act=ACT_NONE, out=None, ident=None):
+    return Conv3x3Fn.apply(x, weight, bias, packed, stride, act, out, ident)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -183,7 +190,7 @@ class AdaINUpCatFn(Function):
     channels [C, C+Cs) of `catbuf` (its producer wrote it there): only channels [0, C) are written."""
 
     @staticmethod
-    def forward(ctx, x, y_std, y_mean, skip, catbuf, eps, p_drop, seed):
+    def forward(ctx, x, y_std, y_mean, skip, catbuf, eps, p_drop, seed, seed_dev=None, mask_in=None):
         require_cuda(x, "adain_upcat")
         code = dtype_code(x)
         n, c, h, w = x.shape
@@ -197,7 +204,7 @@ class AdaINUpCatFn(Function):
         ys = y_std.detach().float().contiguous()
         ym = y_mean.detach().float().contiguous()
         out = catbuf.detach()
-        ctx.mbits = K.adain_upcat(x, stats, ys, ym, out, p_drop, seed, ctx.needs_input_grad[0])
+        ctx.mbits = K.adain_upcat(x, stats, ys, ym, out, p_drop, seed, ctx.needs_input_grad[0], seed_dev, mask_in)
         ctx.save_for_backward(x, stats, ys)
         ctx.meta = (code, float(p_drop), int(seed), cs)
         return out
@@ -211,11 +218,11 @@ class AdaINUpCatFn(Function):
         dx = empty_nhwc(n, c, h, w, x.dtype, x.device)
         d_std, d_mean = K.adain_upcat_bwd(g, x, stats, ys, dx, p_drop, seed, ctx.mbits)
         dskip = g[:, c:] if ctx.needs_input_grad[3] else None     # a channel-slice view: no copy
-        return dx, d_std, d_mean, dskip, None, None, None, None
+        return dx, d_std, d_mean, dskip, None, None, None, None, None, None
 
 
-def adain_upcat(x, y_std, y_mean, skip, catbuf, eps, p_drop, seed):
-    return AdaINUpCatFn.apply(x, y_std, y_mean, skip, catbuf, eps, p_drop, seed)
+def adain_upcat(x, y_std, y_mean, skip, catbuf, eps, p_drop, seed, seed_dev=None, mask_in=None):
+    return AdaINUpCatFn.apply(x, y_std, y_mean, skip, catbuf, eps, p_drop, seed, seed_dev, mask_in)
 
 
 def dropout_mask(n, c, h2, w2, p_drop, seed, device):

@@ -145,17 +145,36 @@ def adain_stats(x, eps):
     return stats
 
 
-def adain_upcat(x, stats, y_std, y_mean, cat, p_drop, seed, want_mask_bits):
-    """Writes channels [0, C) of `cat`; returns the keep-bit tensor (or None)."""
+def adain_upcat(x, stats, y_std, y_mean, cat, p_drop, seed, want_mask_bits, seed_dev=None, mask_in=None):
+    """Writes channels [0, C) of `cat`; returns the keep-bit tensor (or None).
+    ``seed_dev``: optional int64 device scalar added to `seed` inside the kernel (graph-safe per-replay masks);
+    ``mask_in``: optional caller-supplied keep bits (``pack_keep_mask``) used INSTEAD of the counter RNG."""
     n, c, h, w = x.shape
     esz = x.element_size()
+    nbits = n * 4 * h * w * (c * esz // 16)
     mbits = None
-    if p_drop > 0 and want_mask_bits:
-        mbits = torch.empty(n * 4 * h * w * (c * esz // 16), dtype=torch.uint8, device=x.device)
+    if p_drop > 0 and mask_in is not None:
+        if mask_in.dtype != torch.uint8 or mask_in.numel() != nbits or not mask_in.is_contiguous() or mask_in.device != x.device:
+            raise ValueError(f"adain_upcat: mask_in must be {nbits} contiguous uint8 keep-bit bytes on {x.device}")
+        mbits = mask_in
+    elif p_drop > 0 and want_mask_bits:
+        mbits = torch.empty(nbits, dtype=torch.uint8, device=x.device)
     _lib.call("wu_adain_upcat_fwd", x.data_ptr(), nhwc_ld(x), stats.data_ptr(), y_std.data_ptr(), y_mean.data_ptr(),
               cat.data_ptr(), nhwc_ld(cat), n, h, w, c, float(p_drop), int(seed),
-              mbits.data_ptr() if mbits is not None else None, dtype_code(x), stream_ptr())
+              seed_dev.data_ptr() if seed_dev is not None else None,
+              mbits.data_ptr() if mbits is not None else None, 1 if (mask_in is not None and p_drop > 0) else 0,
+              dtype_code(x), stream_ptr())
     return mbits
+
+
+def pack_keep_mask(mask_nchw, dtype):
+    """(N, C, H2, W2) keep-mask (non-zero = keep) -> the kernels' keep-bit bytes: one byte per 16-byte channel chunk of the NHWC
+    tensor, bit e = channel chunk*E + e (E = 8 bf16 / 4 fp32 elements)."""
+    n, c, h2, w2 = mask_nchw.shape
+    e = 16 // torch.empty((), dtype=dtype).element_size()
+    m = (mask_nchw != 0).permute(0, 2, 3, 1).reshape(n, h2, w2, c // e, e).to(torch.int32)
+    weights = (2 ** torch.arange(e, device=mask_nchw.device, dtype=torch.int32))
+    return (m * weights).sum(-1).to(torch.uint8).reshape(-1).contiguous()
 
 
 def adain_upcat_bwd(g_cat, x, stats, y_std, dx, p_drop, seed, mbits, x_gate_act=ACT_NONE):

@@ -1,17 +1,20 @@
 """The GAN training step of the reference on synthetic tensors (BASELINE.json configs[2], configs[3]).
 
 ``WeatherTransferStep`` is the harness counterpart of ``WeatherTransfer.update_discriminator`` /
-``update_inference`` (class-conditioned: t_cls_train.py:226-312; soft-label / estimator-conditioned:
-t_est_train.py:214-283): same order of forwards / backwards, same losses (ops.py), same optimisers
-(Adam lr 1e-4, betas (0, 0.999), weight_decay lr/20, t_cls_train.py:184-185).  Datasets, TensorBoard and the
-pickled ResNet-101 estimator are out of scope: the estimator is a small frozen stand-in
-``(N,3,H,W) -> (N,nc)`` through which gradients flow to the generator, as they do through the real one.
+``update_inference`` / ``evaluation`` (class-conditioned: t_cls_train.py:226-367; soft-label / estimator-conditioned:
+t_est_train.py:214-332): same order of forwards / backwards, same losses (ops.py), same optimisers
+(Adam lr 1e-4, betas (0, 0.999), weight_decay lr/20, t_cls_train.py:184-185), same switches
+(``--supervised`` t_cls_train.py:232-235,260-262,294-297,419-421; ``--cross_ent`` :247-251,256,436).  Datasets and
+TensorBoard are out of scope.  The estimator is any frozen ``nn.Module (N,3,H,W) -> (N,nc)`` RAW outputs
+(what the scripts call ``self.estimator_``) through which gradients flow to the generator: ``wu.resnet.ResNet101Estimator``
+(the architecture of classifier.py:106 / estimator.py:143 on the HIP kernels) or the small ``StandInEstimator``.
 
 Differences from the reference loop, all numerically neutral:
   * update_discriminator runs G under no_grad (the reference builds G's graph and then detaches it,
     t_cls_train.py:302-303);
   * no ``.item()`` host syncs inside the step (the reference forces six per step, :275-282,310-312): losses are
     returned as device tensors;
+  * evaluation() runs its B transfers as ONE (B*B)-image pass of G / D / estimator instead of B passes;
   * data parallel (new): G and D gradients are averaged by two ``GradBucketReducer``s; the D
     gradients that g_loss.backward() deposits (and the next d_opt.zero_grad() discards, t_cls_train.py:291) are
     not all-reduced.
@@ -26,17 +29,14 @@ from wu.ddp import GradBucketReducer, broadcast_buffers, is_distributed, ready_o
 
 
 class StandInEstimator(nn.Module):
-    """Frozen stand-in for the pre-trained ResNet-101 classifier / estimator (classifier.py:106, estimator.py:143;
-    OUT of scope).  ``softmax=True`` mimics the classifier head used by t_cls_train (``self.estimator``, softmax
-    output), ``False`` the 5-signal regression estimator of t_est_train."""
+    """Small frozen stand-in for the pre-trained ResNet-101 (classifier.py:106, estimator.py:143) for tests and for step
+    timings that should exclude the estimator: average pool to 32x32, two dense layers, RAW outputs (no softmax)."""
 
-    def __init__(self, num_classes, softmax=True):
+    def __init__(self, num_classes, softmax=False):
         super().__init__()
-        # The stand-in must not show up in the step time (the real ResNet-101 is out of scope): average pool to 32x32, then two
-        # dense layers -- plain GEMMs, no MIOpen convolution (its im2col / naive fallbacks cost ~3 ms per GAN iteration).
         self.pool = nn.AdaptiveAvgPool2d(32)
         self.features = nn.Sequential(nn.Flatten(), nn.Linear(3 * 32 * 32, 64), nn.ReLU(inplace=True), nn.Linear(64, num_classes))
-        self.softmax = softmax
+        self.softmax = softmax            # legacy switch: fold the classifier's softmax head into the module itself
         for p in self.parameters():
             p.requires_grad_(False)
 
@@ -46,15 +46,25 @@ class StandInEstimator(nn.Module):
 
 
 class WeatherTransferStep:
-    def __init__(self, num_classes=5, mode="cls", precision="bf16", lr=1e-4, device="cuda", ddp=None, seed=0):
+    """``mode="cls"``: t_cls_train.py (``self.estimator`` = Softmax(estimator_), :174-178); ``mode="est"``: t_est_train.py
+    (``self.estimator`` = the raw 5-signal regressor, :165-166).  ``supervised`` / ``cross_ent``: the t_cls_train flags."""
+
+    def __init__(self, num_classes=5, mode="cls", precision="bf16", lr=1e-4, device="cuda", ddp=None, seed=0,
+                 supervised=False, cross_ent=False, estimator=None):
         if mode not in ("cls", "est"):
             raise ValueError("mode must be 'cls' (t_cls_train.py) or 'est' (t_est_train.py)")
+        if mode == "est" and (supervised or cross_ent):
+            raise ValueError("--supervised / --cross_ent exist in t_cls_train.py only")
         self.mode, self.num_classes = mode, num_classes
+        self.supervised, self.cross_ent = bool(supervised), bool(cross_ent)
         dev = torch.device(device)
         torch.manual_seed(seed)
         self.inference = Conditional_UNet(num_classes, precision=precision).to(dev)
         self.discriminator = SNDisc(num_classes, precision=precision).to(dev)
-        self.estimator = StandInEstimator(num_classes, softmax=(mode == "cls")).to(dev).eval()
+        # estimator_ = raw outputs; estimator = what the script calls self.estimator (t_cls_train.py:172-178)
+        self.estimator_ = (estimator if estimator is not None else StandInEstimator(num_classes)).to(dev).eval()
+        for p in self.estimator_.parameters():
+            p.requires_grad_(False)
         self.inference.train()
         self.discriminator.train()
         wd = lr / 20
@@ -67,19 +77,24 @@ class WeatherTransferStep:
             self.d_red = GradBucketReducer(list(self.discriminator.parameters()), bucket_mb=12.0)
             broadcast_buffers(self.discriminator)      # SN weight_u / weight_v identical on every rank
 
+    def estimator(self, x):
+        """``self.estimator`` of the scripts: softmax head in t_cls_train (:174-178), raw in t_est_train."""
+        y = self.estimator_(x)
+        return torch.softmax(y, dim=1) if self.mode == "cls" else y
+
     # ------------------------------------------------------------------ t_cls_train.py:288-312 / t_est_train.py:261-283
-    def update_discriminator(self, images, labels):
+    def update_discriminator(self, images, labels, c_d=None):
         if self.d_red is not None:
             self.d_red.enabled = True
             self.d_red.zero_grad()
         else:
             self.d_opt.zero_grad(set_to_none=True)
         with torch.no_grad():
-            pred_labels = self.estimator(images)
-            fake_out = self.inference(images, labels)
-        real_d_out_pred = self.discriminator(images, pred_labels)[0]
+            pred_labels = c_d if self.supervised else self.estimator(images)             # :294-297
+            fake_out = self.inference(images, labels)                                    # :302-303
+        real_d_out_pred = self.discriminator(images, pred_labels)[0]                     # :299
         fake_d_out = self.discriminator(fake_out, labels)[0]
-        d_loss = ops.dis_hinge(fake_d_out, real_d_out_pred)
+        d_loss = ops.dis_hinge(fake_d_out, real_d_out_pred)                              # :305
         d_loss.backward()
         if self.d_red is not None:
             self.d_red.finalize()
@@ -87,42 +102,97 @@ class WeatherTransferStep:
         return d_loss.detach()
 
     # ------------------------------------------------------------------ t_cls_train.py:226-286 / t_est_train.py:214-259
-    def update_inference(self, images, r_labels):
+    def update_inference(self, images, r_labels, d_labels=None, r_labels_=None):
         if self.g_red is not None:
             self.g_red.zero_grad()
             self.d_red.enabled = False             # D's gradients from this backward are discarded, not reduced
         else:
             self.g_opt.zero_grad(set_to_none=True)
         with torch.no_grad():
-            pred_labels = self.estimator(images)
+            pred_labels = d_labels if self.supervised else self.estimator(images)        # :232-237
         # D's parameter gradients from this backward would be thrown away by the next d_opt.zero_grad()
         # (t_cls_train.py:291): do not compute them (only the data-gradient path through D is needed)
         d_params = list(self.discriminator.parameters())
         for p in d_params:
             p.requires_grad_(False)
         try:
-            fake_out = self.inference(images, r_labels)
-            fake_d_out = self.discriminator(fake_out, r_labels)[0]
+            fake_out = self.inference(images, r_labels)                                  # :242
+            fake_d_out = self.discriminator(fake_out, r_labels)[0]                       # :243-244
         finally:
             for p in d_params:
                 p.requires_grad_(True)
-        fake_c_out = self.estimator(fake_out)
-        g_loss_adv = ops.gen_hinge(fake_d_out)                                   # adversarial
-        g_loss_w = ops.pred_loss(fake_c_out, r_labels)                           # weather prediction (MSE)
+        if self.cross_ent:
+            if r_labels_ is None:
+                raise ValueError("update_inference: --cross_ent needs the class indices r_labels_ (t_cls_train.py:434-438)")
+            fake_c_out = self.estimator_(fake_out)                                       # :248 last layer is not softmax
+        else:
+            fake_c_out = self.estimator(fake_out)                                        # :250
+            r_labels_ = r_labels                                                         # :251
+        g_loss_adv = ops.gen_hinge(fake_d_out)                                           # :254 adversarial
+        g_loss_w = ops.pred_loss(fake_c_out, r_labels_, one_hot=self.cross_ent)          # :256 weather prediction
         diff = torch.mean(torch.abs(fake_out - images), [1, 2, 3])
         lmda = torch.mean(torch.abs(pred_labels - r_labels), 1)
-        loss_con = torch.mean(diff / (lmda + 1e-7))                              # reconstruction
-        g_loss = g_loss_adv + loss_con + g_loss_w
+        loss_con = torch.mean(diff / (lmda + (1e-2 if self.supervised else 1e-7)))       # :260-266 reconstruction
+        g_loss = g_loss_adv + loss_con + g_loss_w                                        # :268-270
         g_loss.backward()
         if self.g_red is not None:
             self.g_red.finalize()
         self.g_opt.step()
         return g_loss.detach(), g_loss_adv.detach(), loss_con.detach(), g_loss_w.detach()
 
-    # ------------------------------------------------------------------ t_cls_train.py:424-438 (one iteration of train())
-    def step(self, images, rand_images):
-        with torch.no_grad():
-            rand_labels = self.estimator(rand_images)
-        d_loss = self.update_discriminator(images, rand_labels)
-        g_losses = self.update_inference(images, rand_labels)
+    # ------------------------------------------------------------------ t_cls_train.py:414-438 (one iteration of train())
+    def step(self, images, rand_images, c_d=None, c_r=None):
+        """One iteration.  ``c_d`` / ``c_r``: class indices of the two batches (needed with ``supervised``; ``c_r`` also
+        feeds ``--cross_ent`` in the i2w branch, :437-438 -- without it the flicker branch :435-436 is taken)."""
+        nc = self.num_classes
+        if self.supervised:
+            if c_d is None or c_r is None:
+                raise ValueError("step: --supervised needs the class indices c_d and c_r (t_cls_train.py:419-421)")
+            eye = torch.eye(nc, device=images.device)
+            rand_labels, d_labels = eye[c_r], eye[c_d]                                   # :420-421
+            r_idx = c_r                                                                  # :432
+        else:
+            with torch.no_grad():
+                raw = self.estimator_(rand_images)
+                rand_labels = torch.softmax(raw, dim=1) if self.mode == "cls" else raw   # :423
+            d_labels = None
+            r_idx = (c_r if c_r is not None else torch.argmax(raw, dim=1)) if self.cross_ent else None   # :436,438
+        d_loss = self.update_discriminator(images, rand_labels, d_labels)                # :429
+        g_losses = self.update_inference(images, rand_labels, d_labels, r_idx)           # :432-438
         return (d_loss,) + g_losses
+
+    # ------------------------------------------------------------------ t_cls_train.py:314-367 / t_est_train.py:285-332
+    @torch.no_grad()
+    def evaluation(self, images, labels, ref_labels, max_images=1024):
+        """The test-time sweep: every image of the batch transferred to every reference row's conditioning, averaged losses.
+        The reference runs B passes of G / estimator / D over the B-image batch; this is ONE pass over the B*B (image,
+        condition) pairs (chunked to ``max_images`` images), D(images, labels) computed once -- identical means, since every
+        per-pass loss is a mean over equally sized blocks.  G / D stay in whatever train / eval mode they are in (the
+        reference never calls .eval(): Dropout and the power iteration are active there).
+        Returns (dict of device scalars g_loss_adv, g_loss_l1, g_loss_w, d_loss; fake images (B, B, 3, H, W): [i] = transfers
+        to ref_labels[i])."""
+        bs, nc = images.shape[0], ref_labels.shape[1]
+        if labels.dim() == 1:                                                            # :327-329 (--one_hot)
+            labels = torch.eye(nc, device=images.device)[labels]
+        real_d = self.discriminator(images, labels)[0]                                   # :340
+        est = self.estimator_ if self.mode == "cls" else self.estimator                  # :338 / t_est_train.py:309
+        rows = max(1, max_images // bs)
+        fakes, fake_d, fake_c = [], [], []
+        for i0 in range(0, bs, rows):
+            r = ref_labels[i0:i0 + rows]
+            cond = r.repeat_interleave(bs, dim=0)                                        # :336 ref_labels[i] tiled B times
+            x = images.repeat(r.shape[0], 1, 1, 1)
+            f = self.inference(x, cond)                                                  # :337
+            fakes.append(f)
+            fake_c.append(est(f))                                                        # :338
+            fake_d.append(self.discriminator(f, cond)[0])                                # :341
+        fake = torch.cat(fakes)
+        cond_all = ref_labels.repeat_interleave(bs, dim=0)
+        fd = torch.cat(fake_d)
+        losses = {
+            "g_loss_adv": ops.gen_hinge(fd),                                             # :349
+            "g_loss_l1": ops.l1_loss(fake, images.repeat(bs, 1, 1, 1)),                  # :350
+            "g_loss_w": ops.pred_loss(torch.cat(fake_c), cond_all),                      # :351
+            "d_loss": ops.dis_hinge(fd, real_d),                                         # :352
+        }
+        return losses, fake.view(bs, bs, *images.shape[1:])

@@ -22,6 +22,7 @@ RELU = K.ACT_RELU
 # data-gradient kernel that follows it and the tails / ramps of the persistent one-workgroup-per-CU launches fill each other.
 SIDE_STREAM_WGRAD = True
 _SIDE = {}
+SIDE_STREAM_LOG = []     # one entry per probe: which candidate won and the median timings (diagnostic)
 
 
 def _side_stream(dev):
@@ -29,26 +30,102 @@ def _side_stream(dev):
     default) round-robin: every fourth stream of the pool shares the current stream's queue and then serialises with it (measured:
     9.8 ms/step instead of 9.5, worse than one stream; which pool index collides depends on what else created streams first,
     e.g. an RCCL communicator).  So the stream is chosen by a one-off probe: a ~0.5 ms single-workgroup spin on the current stream
-    and on each of five candidates -- the candidate whose spin overlaps (shortest wall time) wins."""
+    and on each of five candidates, three rounds each -- the candidate with the shortest MEDIAN wall time (its spin overlaps the
+    main stream's) wins; the choice and the timings are logged once (WU_LOG_SIDE_STREAM=1 prints them)."""
     main = torch.cuda.current_stream(dev)
     key = (dev, main.cuda_stream)
     s = _SIDE.get(key)
     if s is None:
+        import os
+        import statistics
         import time
         cands = [torch.cuda.Stream(device=dev) for _ in range(5)]
         spin = 1_000_000
         torch.cuda._sleep(spin)                      # warm the spin kernel
-        times = []
-        for cand in cands:
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            torch.cuda._sleep(spin)
-            with torch.cuda.stream(cand):
+        times = [[] for _ in cands]
+        for _ in range(3):
+            for i, cand in enumerate(cands):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
                 torch.cuda._sleep(spin)
-            torch.cuda.synchronize(dev)
-            times.append(time.perf_counter() - t0)
-        s = _SIDE[key] = cands[min(range(len(cands)), key=lambda i: times[i])]
+                with torch.cuda.stream(cand):
+                    torch.cuda._sleep(spin)
+                torch.cuda.synchronize(dev)
+                times[i].append(time.perf_counter() - t0)
+        med = [statistics.median(t) for t in times]
+        best = min(range(len(cands)), key=lambda i: med[i])
+        s = _SIDE[key] = cands[best]
+        SIDE_STREAM_LOG.append({"device": str(dev), "chosen": best, "median_ms": [round(m * 1e3, 3) for m in med]})
+        if os.environ.get("WU_LOG_SIDE_STREAM"):
+            print(f"[wu] side stream for {dev}: candidate {best} of {len(cands)}, median spin-pair ms {SIDE_STREAM_LOG[-1]['median_ms']}",
+                  flush=True)
     return s
+
+
+def prepare_side_stream(dev=None):
+    """Run the side-stream probe now (outside any timed region): called by bench.py / the training harness before warm-up."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if dev is None else torch.device(dev)
+    return _side_stream(dev) if SIDE_STREAM_WGRAD else None
+
+
+class _CudaStreamOps:
+    """The three stream operations GradRouter needs, on real HIP streams (tests substitute recording fakes)."""
+
+    def __init__(self, dev):
+        self.dev = dev
+
+    def current(self):
+        return torch.cuda.current_stream(self.dev)
+
+    def use(self, stream):
+        return torch.cuda.stream(stream)
+
+
+class GradRouter:
+    """Where the fused backward's parameter gradients go, and in which stream order they are announced.
+
+    Without a sink (plain autograd): fresh tensors, returned to autograd when the node finishes.  With a gradient sink
+    (wu.ddp.GradBucketReducer.attach): the weight-gradient kernels accumulate straight into the parameters' bucket-view
+    ``.grad`` and each layer is announced (``sink.grad_written``) the moment its kernel is enqueued, so a full bucket's
+    all-reduce runs beside the rest of backward.  A bucket's collective is ordered after the stream that is current when
+    its LAST gradient is announced, and a bucket mixes gradients produced on both streams (weight gradients on the side
+    stream, thin-layer / head gradients on the main one): every announcement is therefore made on the side stream after
+    it has caught up with the main one (side >= main >= every producer enqueued so far).  Host logic only -- the stream
+    operations come in through ``ops`` so the ordering is testable without a GPU (tests/test_ddp_cpu.py)."""
+
+    def __init__(self, sink, sink_params, shapes, alloc, ops, main, side):
+        self.sink, self.SP, self.shapes, self.alloc, self.ops, self.main, self.side = sink, sink_params, shapes, alloc, ops, main, side
+        self.grads = {}
+
+    def bufs(self, iw):
+        """(dw, db, accumulate) for parameters iw, iw+1: fresh tensors handed to autograd, or the bucket views."""
+        if self.sink is None:
+            return self.alloc(self.shapes[iw]), self.alloc(self.shapes[iw + 1]), False
+        # first write after zero_grad() overwrites the zeroed view (no read-modify-write); later ones accumulate
+        SP = self.SP
+        return SP[iw].grad, SP[iw + 1].grad, not (self.sink.fresh(SP[iw]) and self.sink.fresh(SP[iw + 1]))
+
+    def on_side(self, fn):
+        """Run `fn` (kernel launches) on the side stream, ordered after everything enqueued on the main stream so far."""
+        if self.side is None:
+            return fn()
+        self.side.wait_stream(self.main)                  # operands' producers are enqueued on the main stream
+        with self.ops.use(self.side):
+            return fn()
+
+    def done(self, key, iw, dw, db):
+        if self.sink is None:
+            self.grads[key] = (dw, db)
+            return
+        self.grads[key] = (None, None)
+        if self.side is not None and self.ops.current() != self.side:
+            self.side.wait_stream(self.main)
+            with self.ops.use(self.side):
+                self.sink.grad_written(self.SP[iw])
+                self.sink.grad_written(self.SP[iw + 1])
+        else:
+            self.sink.grad_written(self.SP[iw])
+            self.sink.grad_written(self.SP[iw + 1])
 
 
 BLOCKS = ("dconv_down1", "dconv_down2", "dconv_down3", "dconv_down4", "dconv_up3", "dconv_up2", "dconv_up1")
@@ -61,7 +138,8 @@ def _new(n, c, h, w, dt, dev):
 class UNetFn(Function):
     @staticmethod
     def forward(ctx, meta, x, ys3, ym3, ys2, ym2, ys1, ym1, *params):
-        code, p_drop, seeds, eps, packed, sink = meta
+        code, p_drop, seeds, eps, packed, sink, inj, seed_dev = meta
+        inj = inj if inj is not None else (None, None, None)
         dt, dev = torch_dtype(code), x.device
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
@@ -96,15 +174,15 @@ class UNetFn(Function):
         ys = [t.detach().float().contiguous() for t in (ys3, ys2, ys1)]
         ym = [t.detach().float().contiguous() for t in (ym3, ym2, ym1)]
         st3 = K.adain_stats(b4, eps)
-        mb3 = K.adain_upcat(b4, st3, ys[0], ym[0], cat3, p_drop, seeds[0], want_bits)
+        mb3 = K.adain_upcat(b4, st3, ys[0], ym[0], cat3, p_drop, seeds[0], want_bits, seed_dev, inj[0])
         u3a = K.conv3x3(cat3, pk["dconv_up3.0"][0], wb["dconv_up3"][1], _new(n, 256, h // 4, w // 4, dt, dev), 1, RELU)
         u3b = K.conv3x3(u3a, pk["dconv_up3.2"][0], wb["dconv_up3"][3], _new(n, 256, h // 4, w // 4, dt, dev), 1, RELU)
         st2 = K.adain_stats(u3b, eps)
-        mb2 = K.adain_upcat(u3b, st2, ys[1], ym[1], cat2, p_drop, seeds[1], want_bits)
+        mb2 = K.adain_upcat(u3b, st2, ys[1], ym[1], cat2, p_drop, seeds[1], want_bits, seed_dev, inj[1])
         u2a = K.conv3x3(cat2, pk["dconv_up2.0"][0], wb["dconv_up2"][1], _new(n, 128, h // 2, w // 2, dt, dev), 1, RELU)
         u2b = K.conv3x3(u2a, pk["dconv_up2.2"][0], wb["dconv_up2"][3], _new(n, 128, h // 2, w // 2, dt, dev), 1, RELU)
         st1 = K.adain_stats(u2b, eps)
-        mb1 = K.adain_upcat(u2b, st1, ys[2], ym[2], cat1, p_drop, seeds[2], want_bits)
+        mb1 = K.adain_upcat(u2b, st1, ys[2], ym[2], cat1, p_drop, seeds[2], want_bits, seed_dev, inj[2])
         u1a = K.conv3x3(cat1, pk["dconv_up1.0"][0], wb["dconv_up1"][1], _new(n, 64, h, w, dt, dev), 1, RELU)
         u1b = K.conv3x3(u1a, pk["dconv_up1.2"][0], wb["dconv_up1"][3], _new(n, 64, h, w, dt, dev), 1, RELU)
 
@@ -134,49 +212,19 @@ class UNetFn(Function):
         dev, dt = x.device, u1b.dtype
         n, _, h, w = x.shape
         f32 = dict(dtype=torch.float32, device=dev)
-        grads = {}
         sink, SP = ctx.sink, ctx.sink_params
-
-        def grad_bufs(iw):
-            """(dw, db, accumulate) for parameters iw, iw+1: fresh tensors handed to autograd, or the bucket views."""
-            if sink is None:
-                return torch.empty(shapes[iw], **f32), torch.empty(shapes[iw + 1], **f32), False
-            # first write after zero_grad() overwrites the zeroed view (no read-modify-write); later ones accumulate
-            return SP[iw].grad, SP[iw + 1].grad, not (sink.fresh(SP[iw]) and sink.fresh(SP[iw + 1]))
-
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if SIDE_STREAM_WGRAD else None
+        router = GradRouter(sink, SP, shapes, lambda shp: torch.empty(shp, **f32), _CudaStreamOps(dev), main, side)
+        grads, grad_bufs, done = router.grads, router.bufs, router.done
         keep = []          # operands of side-stream kernels stay referenced until the streams are joined
-
-        def done(key, iw, dw, db):
-            if sink is None:
-                grads[key] = (dw, db)
-                return
-            grads[key] = (None, None)
-            # A bucket's all-reduce is ordered after the stream that is current when its LAST gradient is announced, and a
-            # bucket mixes gradients produced on both streams: always announce on the side stream, after it has caught up with
-            # the main one (side >= main >= every producer enqueued so far)
-            if side is not None and torch.cuda.current_stream(dev) != side:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    sink.grad_written(SP[iw])
-                    sink.grad_written(SP[iw + 1])
-            else:
-                sink.grad_written(SP[iw])
-                sink.grad_written(SP[iw + 1])
 
         def wgrad(name, j, xin, gy):
             iw = 4 * BLOCKS.index(name) + j
             dw, db, acc = grad_bufs(iw)
-            if side is None:
-                K.conv3x3_wgrad(xin, gy, dw, db, accumulate=acc)
-                done((name, j), iw, dw, db)
-                return
-            side.wait_stream(main)                    # xin / gy producers are enqueued on the main stream
-            with torch.cuda.stream(side):
-                K.conv3x3_wgrad(xin, gy, dw, db, accumulate=acc)
-                done((name, j), iw, dw, db)           # a sink's all-reduce must order after THIS stream
-            keep.append((xin, gy, dw, db))
+            router.on_side(lambda: (K.conv3x3_wgrad(xin, gy, dw, db, accumulate=acc), done((name, j), iw, dw, db)))
+            if side is not None:
+                keep.append((xin, gy, dw, db))
 
         def block_bwd(name, xin, mid, g_out_gated, need_dx=True):
             """r_double_conv backward given the PRE-GATED gradient of its output; returns dL/d(xin) (ungated)."""
@@ -255,5 +303,12 @@ def unet_forward(net, x, c):
     params.extend((net.conv_last.weight, net.conv_last.bias))
     p = net.dropout.p if net.training else 0.0
     seeds = tuple(net._next_seed(k) for k in (3, 2, 1))
-    meta = (code, float(p), seeds, float(net.adain3.eps), packed, getattr(net, "grad_sink", None))
+    inj = None
+    if p > 0 and getattr(net, "dropout_masks", None) is not None:
+        # caller-supplied keep-masks for the dropouts at cunet.py:61,68,75 (NCHW, non-zero = keep), e.g. masks captured from
+        # the reference's nn.Dropout: the kernels read them instead of drawing from the counter RNG
+        dt = torch_dtype(code)
+        inj = tuple(K.pack_keep_mask(m.to(x.device), dt) for m in net.dropout_masks)
+    meta = (code, float(p), seeds, float(net.adain3.eps), packed, getattr(net, "grad_sink", None), inj,
+            getattr(net, "_seed_dev", None))
     return UNetFn.apply(meta, x, *styles, *params)
