@@ -210,6 +210,40 @@ int wu_dropout_mask(uint8_t* mask_nchw, int N, int H2, int W2, int C, float p_dr
 int wu_sumpool_fwd(const void* x, int ldx, float* feat, int N, int H, int W, int C, int dtype, void* stream);
 int wu_sumpool_bwd(const float* dfeat, void* dx, int lddx, int N, int H, int W, int C, int dtype, void* stream);
 
+/* ---- frozen ResNet-101 estimator in the GAN loop -------------------------------------------------------------------------
+ * The reference runs torchvision.models.resnet101 (classifier.py:106-112, estimator.py:143-151) four times per iteration and
+ * differentiates it once wrt its input (t_cls_train.py:237,247-250,297,424); it is frozen and in eval mode, so every BatchNorm
+ * is a per-channel affine that the caller folds into the conv weight / bias.  The 3x3 convs of the Bottleneck blocks use
+ * wu_conv3x3_fwd / wu_conv3x3_s2_dgrad above; these are the remaining ops.
+ *
+ * 1x1 conv as a GEMM on the matrix cores.  One GEMM row per point (n, hc, wc) of a COARSE grid N x Hc x Wc:
+ *     in  = x[n, hc*in_stride, wc*in_stride, :]      (x: N x Hin x Win x Cin,  pixel stride ldx)
+ *     out = y[n, hc*out_stride, wc*out_stride, :]    (y: N x Hout x Wout x Cout, pixel stride ldy)
+ *     out = act(w . in + bias + residual) * act'(egate)          w: [Cout][Cin] in `dtype`, bias fp32 (may be NULL)
+ * in_stride = 2 is the downsample conv (nn.Conv2d(cin, cout, 1, stride=2)); out_stride = 2 is its data gradient (called with
+ * the transposed weight): the other pixels of each 2x2 output block receive act(residual) * act'(egate), or zero.
+ * `residual` / `egate` (may be NULL) have y's geometry (pixel strides ldres / ldegate).  Cin % (128 / sizeof(T)) == 0,
+ * Cout % 64 == 0. */
+int wu_conv1x1_fwd(const void* x, int ldx, const void* w, const float* bias, const void* residual, int ldres,
+                   void* y, int ldy, int N, int Hc, int Wc, int in_stride, int Hin, int Win,
+                   int out_stride, int Hout, int Wout, int Cin, int Cout, int act,
+                   const void* egate, int ldegate, int egate_act, int dtype, void* stream);
+/* Stem: nn.Conv2d(3, 64, 7, stride=2, padding=3) + folded BN + ReLU from the NCHW fp32 image to NHWC `dtype`
+ * (N, Ho, Wo, 64), Ho = (H-1)/2 + 1; w: OIHW fp32 [64][3][7][7], bias [64] (may be NULL). */
+int wu_stem7x7_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y, int ldy,
+                   int N, int H, int W, int act, int dtype, void* stream);
+/* its data gradient wrt the image (g_loss flows through estimator(fake_out) into the generator, t_cls_train.py:247-250,272):
+ * dx_nchw (N,3,H,W) fp32 (+)= conv_transpose(dy); dy (N,Ho,Wo,64) already gated by the stem's ReLU. */
+int wu_stem7x7_dgrad(const void* dy, int lddy, const float* w_oihw, float* dx_nchw, int N, int H, int W,
+                     int accumulate, int dtype, void* stream);
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1): x (N,H,W,C) -> y (N,Ho,Wo,C); `argmax` (may be NULL; N*Ho*Wo*C bytes)
+ * receives the window-local index 0..8 of the FIRST maximum (PyTorch's tie rule) for the backward pass. */
+int wu_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* argmax, int N, int H, int W, int C,
+                      int dtype, void* stream);
+/* dx (N,H,W,C) = sum over the (overlapping) windows whose arg-max is this pixel of dy; gate_act != 0: * act'(x). */
+int wu_maxpool3s2_bwd(const void* dy, int lddy, const uint8_t* argmax, const void* x, int ldx, void* dx, int lddx,
+                      int N, int H, int W, int C, int gate_act, int dtype, void* stream);
+
 /* layout helpers for the module boundary: NHWC `dtype` <-> NCHW fp32 (feature maps returned by
  * SNDisc.forward, disc.py:38; gradients flowing back into them). */
 int wu_nhwc_to_nchw_f32(const void* x, int ldx, float* y_nchw, int N, int H, int W, int C, int dtype, void* stream);
@@ -226,6 +260,7 @@ int wu_nchw_f32_to_nhwc(const float* x_nchw, void* y, int ldy, int N, int H, int
 #define WU_FAM_CONV_DGRAD 3  /* conv3x3_mfma_kernel<T,1,true>: gated data-gradient pass */
 #define WU_FAM_CONV_S2 4     /* conv3x3_mfma_kernel<T,2,false>: discriminator stride-2 forward */
 #define WU_FAM_WGRAD_S2 5    /* conv3x3_wgrad_kernel<T,2,P> */
+#define WU_FAM_CONV1X1 6     /* conv1x1_mfma_kernel<T>: pointwise convs of the estimator */
 int wu_prof_begin(unsigned family_mask, int max_launches);
 int wu_prof_query(int family, int* launches, double* total_ms, double* total_flops, double* total_bytes);
 int wu_prof_end(void);

@@ -278,79 +278,101 @@ def test_hipgraph_inference_equals_eager():
             eager = net(xd, cd)
         out = g(xd, cd, copy_out=True)
         assert torch.equal(out, eager)
-    net.train()
-    with pytest.raises(ValueError):
-        GraphedUNet(net, batch=2, size=64)
+    # (train-mode = dropout-active graphs: tests/test_gpu_round2.py::test_hipgraph_dropout_active_and_recapture)
 
 
-def test_gan_step_matches_oracle():
-    """One D update + one G update of the t_cls_train loop (t_cls_train.py:226-312) against the CPU oracle with the
-    same weights, inputs and stand-in estimator: losses and the gradients that reach G / D (fp32, dropout off)."""
-    from wu.train_step import WeatherTransferStep
-    import ops
-    nc, seed = 5, 9
-    st = WeatherTransferStep(nc, mode="cls", precision="fp32", device=DEV, ddp=False, seed=1)
+def _gan_case(mode, precision, supervised=False, cross_ent=False, size=64, batch=2, seed=9):
+    """One D update + one G update of the reference loop against the oracle's restatement (oracle/cunet_ref.py
+    update_discriminator_loss / update_inference_loss) with the same weights, inputs and stand-in estimator; lr = 0 so the G
+    update sees the D weights the oracle used.  Returns the worst G / D gradient cosines and the loss errors."""
+    from wu.train_step import WeatherTransferStep, StandInEstimator
+    nc = 5
+    st = WeatherTransferStep(nc, mode=mode, precision=precision, device=DEV, ddp=False, seed=1, supervised=supervised, cross_ent=cross_ent)
     st.inference.load_state_dict(O.make_cunet_params(nc, seed))
     st.discriminator.load_state_dict(O.make_sndisc_params(nc, seed))
     st.inference.eval()                        # dropout identity so the oracle needs no mask
-    x, _ = O.make_inputs(2, 64, nc, seed, True)
-    xr, _ = O.make_inputs(2, 64, nc, seed + 1, True)
-    est = st.estimator
-    est_cpu = type(est)(nc, softmax=True)
-    est_cpu.load_state_dict({k: v.cpu() for k, v in est.state_dict().items()})
+    x, _ = O.make_inputs(batch, size, nc, seed, True)
+    xr, _ = O.make_inputs(batch, size, nc, seed + 1, True)
+    c_d = torch.arange(batch) % nc
+    c_r = (torch.arange(batch) * 2 + 1) % nc
+    est_cpu = StandInEstimator(nc)
+    est_cpu.load_state_dict({k: v.cpu() for k, v in st.estimator_.state_dict().items()})
+    est_raw = est_cpu
+    est_out = (lambda t: torch.softmax(est_cpu(t), 1)) if mode == "cls" else est_cpu      # t_cls_train.py:174-178
     # ---- oracle ----
     gp = {k: v.clone().requires_grad_(True) for k, v in O.make_cunet_params(nc, seed).items()}
     dp = {k: (v.clone().requires_grad_(True) if k.endswith(("weight_orig", "bias")) else v.clone())
           for k, v in O.make_sndisc_params(nc, seed).items()}
+    eye = torch.eye(nc)
     with torch.no_grad():
-        rand_labels = est_cpu(xr)
-        pred = est_cpu(x)
-        fake_nograd = O.cunet_forward(gp, x, rand_labels)
-    real_d, nb1 = O.sndisc_forward(dp, x, pred, train=True)
-    dp2 = dict(dp); dp2.update(nb1)
-    fake_d, nb2 = O.sndisc_forward(dp2, fake_nograd, rand_labels, train=True)
-    d_loss_ref = O.dis_hinge(fake_d[0], real_d[0])
+        if supervised:
+            rand_labels, d_labels, r_idx = eye[c_r], eye[c_d], c_r                        # t_cls_train.py:419-421,432
+        else:
+            raw = est_raw(xr)
+            rand_labels = est_out(xr)                                                    # :423
+            d_labels, r_idx = None, (torch.argmax(raw, 1) if cross_ent else None)        # :436
+    d_loss_ref, nb2 = O.update_discriminator_loss(gp, dp, est_out, x, rand_labels, d_labels, supervised)
     d_loss_ref.backward()
     d_grads = {k: v.grad.clone() for k, v in dp.items() if v.requires_grad}
-    # (the oracle does not apply the optimiser step; compare the G update on the SAME D weights by zero lr below)
+    dp3 = {k: v.detach() for k, v in dp.items()}
+    dp3.update(nb2)                                                                       # D's buffers after two power iterations
+    g_ref = O.update_inference_loss(gp, dp3, est_out, est_raw, x, rand_labels, d_labels, r_idx, supervised, cross_ent)
+    g_ref[0].backward()
     # ---- build ----
-    for g in st.d_opt.param_groups:
-        g["lr"] = 0.0
-        g["weight_decay"] = 0.0
+    for opt in (st.d_opt, st.g_opt):
+        for g in opt.param_groups:
+            g["lr"] = 0.0
+            g["weight_decay"] = 0.0
     xd, xrd = x.to(DEV), xr.to(DEV)
-    with torch.no_grad():
-        rl = st.estimator(xrd)
-    d_loss = st.update_discriminator(xd, rl)
-    assert abs(d_loss.item() - d_loss_ref.item()) <= 2e-3 * max(1.0, abs(d_loss_ref.item()))
+    rl = rand_labels.to(DEV)
+    dl = d_labels.to(DEV) if d_labels is not None else None
+    d_loss = st.update_discriminator(xd, rl, dl)
+    res = {"d_loss_err": abs(d_loss.item() - d_loss_ref.item()) / max(1.0, abs(d_loss_ref.item()))}
+    worst_d = 1.0
     for k, prm in st.discriminator.named_parameters():
         a, b = prm.grad.detach().cpu().reshape(-1).double(), d_grads[k].reshape(-1).double()
-        cos = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
-        assert cos >= 0.999, f"D grad {k}: cos {cos}"
-    # ---- G update: D's buffers have advanced by two power iterations (nb2) ----
-    dp3 = {k: v.detach() for k, v in dp.items()}
-    dp3.update(nb2)
-    fake = O.cunet_forward(gp, x, rand_labels)
-    fd, _ = O.sndisc_forward(dp3, fake, rand_labels, train=True)
-    fc = est_cpu(fake)
-    diff = torch.mean(torch.abs(fake - x), [1, 2, 3])
-    lm = torch.mean(torch.abs(pred - rand_labels), 1)
-    g_ref = O.gen_hinge(fd[0]) + torch.mean(diff / (lm + 1e-7)) + torch.nn.functional.mse_loss(fc, rand_labels)
-    g_ref.backward()
-    for g in st.g_opt.param_groups:
-        g["lr"] = 0.0
-        g["weight_decay"] = 0.0
-    g_loss = st.update_inference(xd, rl)[0]
-    assert abs(g_loss.item() - g_ref.item()) <= 2e-3 * max(1.0, abs(g_ref.item())), (g_loss.item(), g_ref.item())
-    worst = 1.0
+        worst_d = min(worst_d, (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item())
+    g_losses = st.update_inference(xd, rl, dl, r_idx.to(DEV) if r_idx is not None else None)
+    res["g_loss_err"] = abs(g_losses[0].item() - g_ref[0].item()) / max(1.0, abs(g_ref[0].item()))
+    res["g_parts_err"] = max(abs(g_losses[i].item() - g_ref[i].item()) / max(1.0, abs(g_ref[i].item())) for i in (1, 2, 3))
+    worst_g = 1.0
+    per_layer = {}
     for k, prm in st.inference.named_parameters():
         if prm.grad is None:
             continue
         a, b = prm.grad.detach().cpu().reshape(-1).double(), gp[k].grad.reshape(-1).double()
-        cos = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
-        worst = min(worst, cos)
-        assert cos >= 0.995, f"G grad {k}: cos {cos}"
-    assert all(p.grad is None or True for p in st.discriminator.parameters())
-    print("GAN step: worst G-gradient cosine", worst)
+        per_layer[k] = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
+        worst_g = min(worst_g, per_layer[k])
+    res.update(worst_d=worst_d, worst_g=worst_g, per_layer=per_layer)
+    return res
+
+
+@pytest.mark.parametrize("mode,supervised,cross_ent", [("cls", False, False), ("est", False, False),
+                                                       ("cls", True, False), ("cls", False, True), ("cls", True, True)])
+def test_gan_step_matches_oracle(mode, supervised, cross_ent):
+    """fp32: the t_cls_train step (t_cls_train.py:226-312) incl. its --supervised (:232-235,260-262,294-297) and --cross_ent
+    (:247-251,256,436) switches, and the t_est_train soft-label step (t_est_train.py:214-283, BASELINE configs[3]: raw
+    5-signal estimator outputs as conditioning, MSE weather loss) against the CPU oracle's autograd."""
+    r = _gan_case(mode, "fp32", supervised, cross_ent)
+    print(f"GAN step {mode} sup={supervised} ce={cross_ent}: d_loss err {r['d_loss_err']:.2e}, g_loss err {r['g_loss_err']:.2e}, "
+          f"worst D cos {r['worst_d']:.8f}, worst G cos {r['worst_g']:.8f}")
+    assert r["d_loss_err"] <= 2e-3 and r["g_loss_err"] <= 2e-3 and r["g_parts_err"] <= 2e-3
+    assert r["worst_d"] >= 0.999 and r["worst_g"] >= 0.995
+
+
+@pytest.mark.parametrize("mode", ["cls", "est"])
+def test_gan_step_bf16(mode):
+    """The same two steps in the bf16 production mode (configs[2] / configs[3] arithmetic).  Tolerances: losses within 5e-2
+    relative (north_star's bf16 forward tolerance; the hinge / reconstruction terms are means of O(1) values), D gradients
+    cosine >= 0.98, G gradients cosine >= 0.9 (they cross D, the estimator and ~30 bf16-rounded gated ops; the per-layer
+    figures are printed; the tight bf16 check of G's own backward is test_bf16_gradients_vs_emulating_oracle)."""
+    r = _gan_case(mode, "bf16")
+    print(f"bf16 GAN step {mode}: d_loss err {r['d_loss_err']:.2e}, g_loss err {r['g_loss_err']:.2e}, worst D cos {r['worst_d']:.5f}, "
+          f"worst G cos {r['worst_g']:.5f}")
+    for k, v in r["per_layer"].items():
+        print(f"   {k:24s} cos {v:.5f}")
+    assert r["d_loss_err"] <= 5e-2 and r["g_loss_err"] <= 5e-2
+    assert r["worst_d"] >= 0.98 and r["worst_g"] >= 0.9
 
 
 def test_checkpoint_interchange_and_class_sweep(tmp_path):
@@ -426,10 +448,17 @@ def test_full_size_properties():
     o32, g32 = run(net32, xs, cs)
     o16, g16 = run(net, xs, cs)
     assert (o32 - o16).abs().max().item() <= FWD_TOL["bf16"]
-    for k in ("dconv_up1.2.weight", "dconv_up1.0.weight", "dconv_up3.0.weight", "dconv_down4.2.weight", "conv_last.weight"):
+    # ALL 36 gradients (weights and biases of the 15 convs, the three AdaIN style layers), per-layer cosine printed.  The fp32
+    # run is a different precision mode of the same kernels' algorithms, so ReLU / max-pool decisions flipped by bf16 rounding
+    # bound the cosine from above (the tight bf16 check is test_gpu_round2.py::test_bf16_gradients_vs_emulating_oracle): decoder
+    # and head >= 0.97, encoder (whose gradients cross ~25 gated ops) >= 0.9.
+    assert len(g16) == 36 and set(g16) == set(g32)
+    for k in g16:
         a, b = g16[k].double().reshape(-1), g32[k].double().reshape(-1)
         cos = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
-        assert cos >= 0.97, f"{k}: cosine {cos}"
+        print(f"   256x256 bf16 vs fp32 kernels  {k:24s} cos {cos:.5f}")
+        lim = 0.97 if k.startswith(("dconv_up", "conv_last")) else 0.9
+        assert cos >= lim, f"{k}: cosine {cos}"
 
 
 def test_fused_backward_gradient_sink():

@@ -120,3 +120,21 @@ def test_batched_evaluation_identity():
     assert torch.allclose(fake.view(bs, bs, 3, 32, 32), torch.stack(fakes), atol=1e-5)
     for k in looped:
         assert abs(looped[k] - batched[k]) <= 1e-5 * max(1.0, abs(looped[k])), (k, looped[k], batched[k])
+
+
+def test_resnet_estimator_state_dict_keys_are_torchvisions():
+    """wu.resnet.ResNet101Estimator keeps torchvision's module names, so a torchvision resnet101 state-dict loads unchanged
+    (classifier.py:106-112 / estimator.py:143-151 build that model); checked against the oracle's restatement of the key list."""
+    from oracle import resnet_ref as R
+    from wu.resnet import ResNet101Estimator
+    net = ResNet101Estimator(5)
+    have = {k: tuple(v.shape) for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
+    want = R.resnet101_param_shapes(5)
+    assert have == want and len(want) == 522                     # torchvision resnet101: 626 entries incl. 104 num_batches_tracked
+    # the one published number the restatement can be held to: torchvision's resnet101 has 44,549,160 parameters (1000 classes)
+    assert sum(int(np.prod(s)) for k, s in R.resnet101_param_shapes(1000).items() if not k.endswith(("running_mean", "running_var"))) == 44_549_160
+    assert not any(p.requires_grad for p in net.parameters()) and not net.training
+    net.train()
+    assert not net.training                                      # frozen for good (t_cls_train.py:173,178)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 3, 64, 64))

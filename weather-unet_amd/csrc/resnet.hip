@@ -1,0 +1,507 @@
+// Kernels of the frozen ResNet-101 estimator that the reference's GAN loop calls four times per iteration and differentiates
+// once with respect to its input (t_cls_train.py:237,247-250,297,424; the model is torchvision.models.resnet101, built at
+// classifier.py:106-112 / estimator.py:143-151, eval mode, BatchNorm therefore a per-channel affine that is folded into the
+// conv weights and bias by the host):
+//   * conv1x1_mfma_kernel   the pointwise convs of the Bottleneck blocks (2/3 of the network's FLOPs) as a plain GEMM on the
+//                           matrix cores: rows = pixels, bias + residual add + ReLU (+ the ReLU gate of the data-gradient
+//                           pass) in a direct register epilogue; stride-2 gather (downsample conv) and stride-2 scatter (its
+//                           data gradient) are row-address maps;
+//   * stem7x7_*             the 7x7 stride-2 stem conv (K = 147) straight from the NCHW fp32 image, and its data gradient;
+//   * maxpool3s2_*          the 3x3 stride-2 max-pool with stored arg-max (windows overlap: backward is a gather over the
+//                           <= 4 windows that contain a pixel).
+// The 3x3 convs of the blocks run on the conv3x3 kernels of this library (conv3x3_mfma_v2.hip / conv3x3_mfma.hip).
+#include <type_traits>
+
+#include "wu_common.h"
+
+namespace {
+
+__host__ __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+
+// =================================================================================================
+// 1x1 conv = GEMM   y[m][co] = act(sum_ci x[row(m)][ci] * w[co][ci] + bias[co] + residual[m][co]) [* act'(egate[m][co])]
+// =================================================================================================
+constexpr int kTM = 256;        // pixels per workgroup
+constexpr int kTN = 64;         // output channels per workgroup
+constexpr int kKB = 128;        // bytes of K staged per step and row (64 bf16 / 32 fp32 channels)
+
+struct PwArgs {
+    const void* x; const void* w; const float* bias; const void* res; void* y; const void* egate;
+    int ldx, ldres, ldy, ldegate;
+    int N, Hc, Wc, in_stride, Hin, Win, out_stride, Hout, Wout, Cin, Cout, act, egate_act;
+    long long M;                // N * Hc * Wc
+    int n_tiles;                // Cout / 64
+};
+
+template <typename T> struct PwMma;
+template <> struct PwMma<bf16_t> {
+    static __device__ __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct PwMma<float> {      // exact fp32: four 32x32x2 steps per 16-byte fragment pair (same k permutation on both operands)
+    static __device__ __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+// LDS image: 128-byte rows, the eight 16-byte slots of a row XOR-swizzled with (row & 7): a ds_read_b128 of 8 consecutive rows at
+// one logical slot touches all 32 banks once
+__device__ __forceinline__ int pw_off(int row, int slot) { return row * kKB + ((slot ^ (row & 7)) << 4); }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[(kTM + kTN) * kKB];      // 40 KiB: two workgroups per CU cover each other's barriers
+    constexpr int E16 = 16 / (int)sizeof(T);                                    // elements per 16-byte slot
+    constexpr int KE = kKB / (int)sizeof(T);                                    // channels per K step
+    char* a_lds = smem;
+    char* w_lds = smem + kTM * kKB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // cout tile fastest: the workgroups that share one pixel tile are neighbours in launch order (same XCD after the remap)
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = bid % a.n_tiles;
+    const long long m0 = (long long)(bid / a.n_tiles) * kTM;
+    const int co0 = ct * kTN;
+
+    auto in_pixel = [&](long long m) __attribute__((always_inline)) -> long long {   // GEMM row -> pixel index of x (or -1)
+        if (m >= a.M) return -1;
+        if (a.in_stride == 1) return m;
+        const int wc = (int)(m % a.Wc);
+        const long long t = m / a.Wc;
+        const int hc = (int)(t % a.Hc);
+        const long long n = t / a.Hc;
+        return (n * a.Hin + (long long)hc * a.in_stride) * a.Win + (long long)wc * a.in_stride;
+    };
+
+    // ---- staging: 8 activation items + 2 weight items of 16 B per thread and K step ----
+    const int srow = tid >> 3, sslot = tid & 7;
+    const T* asrc[8];
+    bool aok[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long long pix = in_pixel(m0 + srow + 32 * k);
+        aok[k] = pix >= 0;
+        asrc[k] = (const T*)a.x + (aok[k] ? pix : 0) * a.ldx + sslot * E16;      // clamped: loads are unconditional, zeroed afterwards
+    }
+    const T* wsrc[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) wsrc[k] = (const T*)a.w + (size_t)(co0 + srow + 32 * k) * a.Cin + sslot * E16;
+
+    uint4 areg[8], wreg[2];
+    auto load_step = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) areg[k] = *(const uint4*)(asrc[k] + c0);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) wreg[k] = *(const uint4*)(wsrc[k] + c0);
+    };
+    auto store_step = [&]() __attribute__((always_inline)) {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) *(uint4*)(a_lds + pw_off(srow + 32 * k, sslot)) = aok[k] ? areg[k] : z;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) *(uint4*)(w_lds + pw_off(srow + 32 * k, sslot)) = wreg[k];
+    };
+
+    // accumulators TRANSPOSED (weights are the MFMA A operand): a lane owns 4 consecutive channels of one pixel per register quad
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+    const int nsteps = a.Cin / KE;
+    load_step(0);
+    store_step();
+    __syncthreads();
+    for (int c = 0; c < nsteps; ++c) {
+        if (c + 1 < nsteps) load_step((c + 1) * KE);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 af[2], bf[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) af[mi] = *(const uint4*)(a_lds + pw_off(64 * wave + 32 * mi + l31, 2 * ks + lh));
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bf[ni] = *(const uint4*)(w_lds + pw_off(32 * ni + l31, 2 * ks + lh));
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) PwMma<T>::run(acc[mi][ni], bf[ni], af[mi]);      // D^T = W * X^T
+        }
+        __syncthreads();
+        if (c + 1 < nsteps) {
+            store_step();
+            __syncthreads();
+        }
+    }
+
+    // ---- direct register epilogue: bias + residual in fp32, activation, gate, 8-byte (bf16) / 16-byte (fp32) stores ----
+    const int os = a.out_stride;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const long long m = m0 + 64 * wave + 32 * mi + l31;
+        if (m >= a.M) continue;
+        long long opix = m;
+        int hc = 0, wc = 0;
+        if (os != 1) {
+            wc = (int)(m % a.Wc);
+            const long long t = m / a.Wc;
+            hc = (int)(t % a.Hc);
+            const long long n = t / a.Hc;
+            opix = (n * a.Hout + (long long)hc * os) * a.Wout + (long long)wc * os;
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = co0 + 32 * ni + 8 * g + 4 * lh;
+                float v[4];
+                const float4 bv = a.bias ? *(const float4*)(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[0] = acc[mi][ni][4 * g + 0] + bv.x; v[1] = acc[mi][ni][4 * g + 1] + bv.y;
+                v[2] = acc[mi][ni][4 * g + 2] + bv.z; v[3] = acc[mi][ni][4 * g + 3] + bv.w;
+                // the pixel itself, then (stride-2 scatter) the other pixels of its block, which receive residual-or-zero
+                for (int dy = 0; dy < os; ++dy)
+                    for (int dx = 0; dx < os; ++dx) {
+                        if (os != 1 && (hc * os + dy >= a.Hout || wc * os + dx >= a.Wout)) continue;
+                        const long long p = opix + (long long)dy * a.Wout + dx;
+                        float o[4];
+                        const bool own = dy == 0 && dx == 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = own ? v[e] : 0.f;
+                        if (a.res) {
+                            const T* rp = (const T*)a.res + p * a.ldres + co;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] += ElemTraits<T>::load(rp + e);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = act_apply(o[e], a.act);
+                        if (a.egate) {
+                            const T* ep = (const T*)a.egate + p * a.ldegate + co;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = act_gate(o[e], ElemTraits<T>::load(ep + e), a.egate_act);
+                        }
+                        T* yp = (T*)a.y + p * a.ldy + co;
+                        if constexpr (std::is_same<T, float>::value) {
+                            *(float4*)yp = make_float4(o[0], o[1], o[2], o[3]);
+                        } else {
+                            *(uint2*)yp = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                        }
+                    }
+            }
+    }
+}
+
+// =================================================================================================
+// stem: conv 7x7, stride 2, pad 3, 3 -> 64, + bias + ReLU, NCHW fp32 image -> NHWC T
+// =================================================================================================
+// One workgroup = 8 x 32 output pixels x 64 channels: the 21 x 69 x 3 input patch and the [147][64] weights sit in LDS, every
+// thread owns one output pixel and all 64 channels (64 fp32 accumulators); weights are read as wave-uniform (broadcast) 16-byte
+// LDS loads, so the inner loop is 1 patch read + 16 broadcast reads per 64 FMAs.
+constexpr int kSTH = 8, kSTW = 32, kSPH = 2 * kSTH + 5, kSPW = 2 * kSTW + 5;     // patch 21 x 69
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem7x7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          T* __restrict__ y, int ldy, int N, int H, int W, int Ho, int Wo, int act) {
+    __shared__ float patch[3][kSPH][kSPW + 1];
+    __shared__ __attribute__((aligned(16))) float wl[147][64];        // [c*49 + kh*7 + kw][co]
+    const int tid = threadIdx.x;
+    const int tiles_x = cdiv_dev(Wo, kSTW), tiles_y = cdiv_dev(Ho, kSTH);
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int oh0 = ty * kSTH, ow0 = tx * kSTW;
+    const int ih0 = 2 * oh0 - 3, iw0 = 2 * ow0 - 3;
+    for (int i = tid; i < 147 * 64; i += 256) {
+        const int co = i & 63, k = i >> 6;
+        wl[k][co] = w[co * 147 + k];                                  // OIHW [64][3][7][7] -> [k][co]
+    }
+    for (int i = tid; i < 3 * kSPH * kSPW; i += 256) {
+        const int px = i % kSPW, t = i / kSPW;
+        const int py = t % kSPH, c = t / kSPH;
+        const int ih = ih0 + py, iw = iw0 + px;
+        const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
+        const float v = x[((size_t)(n * 3 + c) * H + min(max(ih, 0), H - 1)) * W + min(max(iw, 0), W - 1)];
+        patch[c][py][px] = ok ? v : 0.f;
+    }
+    __syncthreads();
+    const int py0 = 2 * (tid >> 5), px0 = 2 * (tid & 31);
+    float acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+    for (int c = 0; c < 3; ++c)
+        for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                const float xv = patch[c][py0 + kh][px0 + kw];
+                const float4* wr = (const float4*)wl[c * 49 + kh * 7 + kw];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float4 wv = wr[q];
+                    acc[4 * q + 0] = fmaf(xv, wv.x, acc[4 * q + 0]); acc[4 * q + 1] = fmaf(xv, wv.y, acc[4 * q + 1]);
+                    acc[4 * q + 2] = fmaf(xv, wv.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(xv, wv.w, acc[4 * q + 3]);
+                }
+            }
+    const int oh = oh0 + (tid >> 5), ow = ow0 + (tid & 31);
+    if (oh < Ho && ow < Wo) {
+        T* yp = y + ((size_t)(n * Ho + oh) * Wo + ow) * ldy;
+        constexpr int E = ElemTraits<T>::kPer16B;
+#pragma unroll
+        for (int q = 0; q < 64 / E; ++q) {
+            float o[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) o[e] = act_apply(acc[q * E + e] + (bias ? bias[q * E + e] : 0.f), act);
+            *(uint4*)(yp + q * E) = pack16<T>(o);
+        }
+    }
+}
+
+// data gradient of the stem wrt the NCHW fp32 image: dx[n][c][ih][iw] = sum_{co, kh, kw : (ih+3-kh, iw+3-kw) even} dy[n][oh][ow][co] w[co][c][kh][kw]
+// 8 lanes per input pixel (each 8 of the 64 channels), the partial sums of the 3 image channels folded with xor shuffles.
+template <typename T>
+__global__ __launch_bounds__(256) void stem7x7_dgrad_kernel(const T* __restrict__ dy, int lddy, const float* __restrict__ w,
+                                                            float* __restrict__ dx, int N, int H, int W, int Ho, int Wo, int accumulate) {
+    __shared__ float wl[49][3][64];                                    // [kh*7+kw][c][co]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 147 * 64; i += 256) {
+        const int co = i & 63, k = i >> 6;            // k = c*49 + tap
+        wl[k % 49][k / 49][co] = w[co * 147 + k];
+    }
+    __syncthreads();
+    const int sub = tid & 7;                                           // channel octet
+    const long long total = (long long)N * H * W;
+    for (long long pix = (long long)blockIdx.x * 32 + (tid >> 3); pix < total; pix += (long long)gridDim.x * 32) {
+        const int iw = (int)(pix % W);
+        const long long t = pix / W;
+        const int ih = (int)(t % H);
+        const int n = (int)(t / H);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        // kh must have the parity of ih + 3 (so that ih + 3 - kh = 2 * oh)
+        for (int kh = (ih + 3) & 1; kh < 7; kh += 2) {
+            const int oh = (ih + 3 - kh) >> 1;
+            if (oh < 0 || oh >= Ho) continue;
+            for (int kw = (iw + 3) & 1; kw < 7; kw += 2) {
+                const int ow = (iw + 3 - kw) >> 1;
+                if (ow < 0 || ow >= Wo) continue;
+                const T* gp = dy + ((size_t)(n * Ho + oh) * Wo + ow) * lddy + sub * 8;
+                float g[8];
+                if constexpr (std::is_same<T, float>::value) {
+                    const float4 a0 = *(const float4*)gp, a1 = *(const float4*)(gp + 4);
+                    g[0] = a0.x; g[1] = a0.y; g[2] = a0.z; g[3] = a0.w; g[4] = a1.x; g[5] = a1.y; g[6] = a1.z; g[7] = a1.w;
+                } else {
+                    unpack16<T>(*(const uint4*)gp, g);
+                }
+                const float* wp = &wl[kh * 7 + kw][0][sub * 8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s0 = fmaf(g[e], wp[e], s0);
+                    s1 = fmaf(g[e], wp[64 + e], s1);
+                    s2 = fmaf(g[e], wp[128 + e], s2);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off);
+        }
+        if (sub < 3) {
+            const float v = sub == 0 ? s0 : (sub == 1 ? s1 : s2);
+            float* dp = dx + ((size_t)(n * 3 + sub) * H + ih) * W + iw;
+            *dp = accumulate ? *dp + v : v;
+        }
+    }
+}
+
+// =================================================================================================
+// MaxPool2d(kernel 3, stride 2, pad 1), NHWC, with the window-local arg-max (0..8, first maximum in scan order) kept for backward
+// =================================================================================================
+template <typename T>
+__global__ void maxpool3s2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, uint8_t* __restrict__ idx,
+                                      int N, int H, int W, int Ho, int Wo, int C) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int cpp = C / E;
+    const long long total = (long long)N * Ho * Wo * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpp);
+        long long p = i / cpp;
+        const int ow = (int)(p % Wo); p /= Wo;
+        const int oh = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float m[E];
+        int am[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { m[e] = -INFINITY; am[e] = 0; }
+        bool first = true;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
+                if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+                float v[E];
+                unpack16<T>(*(const uint4*)(x + ((size_t)(n * H + ih) * W + iw) * ldx + ch * E), v);
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (first || v[e] > m[e] || v[e] != v[e]) { m[e] = v[e]; am[e] = kh * 3 + kw; }
+                first = false;
+            }
+        const size_t o = ((size_t)(n * Ho + oh) * Wo + ow);
+        *(uint4*)(y + o * ldy + ch * E) = pack16<T>(m);
+        if (idx) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) idx[o * C + ch * E + e] = (uint8_t)am[e];
+        }
+    }
+}
+
+// dx[pixel] = sum over the <= 4 windows containing it whose arg-max is this pixel of dy[window]; optionally * act'(x)
+template <typename T>
+__global__ void maxpool3s2_bwd_kernel(const T* __restrict__ dy, int lddy, const uint8_t* __restrict__ idx, const T* __restrict__ x, int ldx,
+                                      T* __restrict__ dx, int lddx, int N, int H, int W, int Ho, int Wo, int C, int gate_act) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int cpp = C / E;
+    const long long total = (long long)N * H * W * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpp);
+        long long p = i / cpp;
+        const int iw = (int)(p % W); p /= W;
+        const int ih = (int)(p % H);
+        const int n = (int)(p / H);
+        float g[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) g[e] = 0.f;
+        // windows oh with 2*oh - 1 <= ih <= 2*oh + 1
+        for (int oh = (ih >> 1); oh <= ((ih + 1) >> 1); ++oh) {
+            if (oh < 0 || oh >= Ho) continue;
+            const int kh = ih - (2 * oh - 1);
+            for (int ow = (iw >> 1); ow <= ((iw + 1) >> 1); ++ow) {
+                if (ow < 0 || ow >= Wo) continue;
+                const int kw = iw - (2 * ow - 1);
+                const size_t o = ((size_t)(n * Ho + oh) * Wo + ow);
+                float d[E];
+                unpack16<T>(*(const uint4*)(dy + o * lddy + ch * E), d);
+                const uint8_t* ip = idx + o * C + ch * E;
+#pragma unroll
+                for (int e = 0; e < E; ++e) g[e] += (ip[e] == kh * 3 + kw) ? d[e] : 0.f;
+            }
+        }
+        const size_t pin = ((size_t)(n * H + ih) * W + iw);
+        if (gate_act != WU_ACT_NONE) {
+            float xv[E];
+            unpack16<T>(*(const uint4*)(x + pin * ldx + ch * E), xv);
+#pragma unroll
+            for (int e = 0; e < E; ++e) g[e] = act_gate(g[e], xv[e], gate_act);
+        }
+        *(uint4*)(dx + pin * lddx + ch * E) = pack16<T>(g);
+    }
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+inline int grid_cap(long long total, int block = 256, int cap = 256 * 16) {
+    long long g = (total + block - 1) / block;
+    return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                                      \
+    do {                                                            \
+        if ((dtype) == WU_BF16) { using T = bf16_t; __VA_ARGS__; }  \
+        else { using T = float; __VA_ARGS__; }                      \
+    } while (0)
+
+extern "C" int wu_conv1x1_fwd(const void* x, int ldx, const void* w, const float* bias, const void* residual, int ldres,
+                              void* y, int ldy, int N, int Hc, int Wc, int in_stride, int Hin, int Win,
+                              int out_stride, int Hout, int Wout, int Cin, int Cout, int act,
+                              const void* egate, int ldegate, int egate_act, int dtype, void* stream) {
+    WU_REQUIRE(dtype == WU_F32 || dtype == WU_BF16, "conv1x1_fwd: bad dtype %d", dtype);
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    const int ke = kKB / esz;
+    WU_REQUIRE(N > 0 && Hc > 0 && Wc > 0, "conv1x1_fwd: empty shape");
+    WU_REQUIRE(Cin > 0 && Cin % ke == 0, "conv1x1_fwd: Cin=%d must be a multiple of %d", Cin, ke);
+    WU_REQUIRE(Cout > 0 && Cout % kTN == 0, "conv1x1_fwd: Cout=%d must be a multiple of %d", Cout, kTN);
+    WU_REQUIRE((in_stride == 1 || in_stride == 2) && (out_stride == 1 || out_stride == 2) && !(in_stride == 2 && out_stride == 2),
+               "conv1x1_fwd: strides (%d,%d)", in_stride, out_stride);
+    WU_REQUIRE((Hc - 1) * in_stride < Hin && (Wc - 1) * in_stride < Win && (Hc - 1) * out_stride < Hout && (Wc - 1) * out_stride < Wout,
+               "conv1x1_fwd: coarse grid %dx%d does not fit input %dx%d / output %dx%d", Hc, Wc, Hin, Win, Hout, Wout);
+    WU_REQUIRE(out_stride == 1 ? (Hout == Hc && Wout == Wc) : (Hout <= 2 * Hc && Wout <= 2 * Wc), "conv1x1_fwd: output %dx%d is not covered by the coarse grid", Hout, Wout);
+    WU_REQUIRE(ldx >= Cin && ldy >= Cout && (ldx * esz) % 16 == 0 && (ldy * esz) % 16 == 0 && al16(x) && al16(y) && al16(w), "conv1x1_fwd: bad ld / alignment");
+    if (residual) WU_REQUIRE(ldres >= Cout && (ldres * esz) % 16 == 0 && al16(residual), "conv1x1_fwd: bad residual");
+    if (egate) WU_REQUIRE(ldegate >= Cout && (ldegate * esz) % 16 == 0 && al16(egate), "conv1x1_fwd: bad egate");
+    if (bias) WU_REQUIRE(al16(bias), "conv1x1_fwd: bias alignment");
+    PwArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y; a.egate = egate;
+    a.ldx = ldx; a.ldres = ldres; a.ldy = ldy; a.ldegate = ldegate;
+    a.N = N; a.Hc = Hc; a.Wc = Wc; a.in_stride = in_stride; a.Hin = Hin; a.Win = Win; a.out_stride = out_stride; a.Hout = Hout; a.Wout = Wout;
+    a.Cin = Cin; a.Cout = Cout; a.act = act; a.egate_act = egate_act;
+    a.M = (long long)N * Hc * Wc;
+    a.n_tiles = Cout / kTN;
+    const long long grid = ((a.M + kTM - 1) / kTM) * a.n_tiles;
+    WU_REQUIRE(grid < (1ll << 31), "conv1x1_fwd: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    wu_prof_pre(WU_FAM_CONV1X1, s);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(conv1x1_mfma_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s, a));
+    wu_prof_post(WU_FAM_CONV1X1, s, 2.0 * (double)a.M * Cin * Cout, ((double)a.M * (Cin + Cout * (residual ? 2 : 1)) + (double)Cin * Cout) * esz);
+    WU_LAUNCH_CHECK("conv1x1_mfma");
+    return 0;
+}
+
+extern "C" int wu_stem7x7_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y, int ldy,
+                              int N, int H, int W, int act, int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    WU_REQUIRE(N > 0 && H >= 7 && W >= 7 && x_nchw && w_oihw && y, "stem7x7_fwd: bad shape");
+    WU_REQUIRE(ldy >= 64 && (ldy * esz) % 16 == 0 && al16(y), "stem7x7_fwd: bad output ld / alignment");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;                     // (H + 6 - 7) / 2 + 1
+    const long long grid = (long long)N * cdiv(Ho, kSTH) * cdiv(Wo, kSTW);
+    WU_REQUIRE(grid < (1ll << 31), "stem7x7_fwd: grid too large");
+    DISPATCH_T(dtype, hipLaunchKernelGGL(stem7x7_fwd_kernel<T>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                                         x_nchw, w_oihw, bias, (T*)y, ldy, N, H, W, Ho, Wo, act));
+    WU_LAUNCH_CHECK("stem7x7_fwd");
+    return 0;
+}
+
+extern "C" int wu_stem7x7_dgrad(const void* dy, int lddy, const float* w_oihw, float* dx_nchw, int N, int H, int W,
+                                int accumulate, int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    WU_REQUIRE(N > 0 && H >= 7 && W >= 7 && dy && w_oihw && dx_nchw, "stem7x7_dgrad: bad shape");
+    WU_REQUIRE(lddy >= 64 && (lddy * esz) % 16 == 0 && al16(dy), "stem7x7_dgrad: bad ld / alignment");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long pixels = (long long)N * H * W;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(stem7x7_dgrad_kernel<T>, dim3(grid_cap(pixels, 32, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)dy, lddy, w_oihw, dx_nchw, N, H, W, Ho, Wo, accumulate));
+    WU_LAUNCH_CHECK("stem7x7_dgrad");
+    return 0;
+}
+
+extern "C" int wu_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* argmax, int N, int H, int W, int C,
+                                 int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    WU_REQUIRE(N > 0 && H > 0 && W > 0 && C % (16 / esz) == 0 && C <= ldx && C <= ldy, "maxpool3s2_fwd: bad shape");
+    WU_REQUIRE(al16(x) && al16(y) && (ldx * esz) % 16 == 0 && (ldy * esz) % 16 == 0, "maxpool3s2_fwd: alignment");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * (C / (16 / esz));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool3s2_fwd_kernel<T>, dim3(grid_cap(total)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)x, ldx, (T*)y, ldy, argmax, N, H, W, Ho, Wo, C));
+    WU_LAUNCH_CHECK("maxpool3s2_fwd");
+    return 0;
+}
+
+extern "C" int wu_maxpool3s2_bwd(const void* dy, int lddy, const uint8_t* argmax, const void* x, int ldx, void* dx, int lddx,
+                                 int N, int H, int W, int C, int gate_act, int dtype, void* stream) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    WU_REQUIRE(N > 0 && H > 0 && W > 0 && C % (16 / esz) == 0 && argmax, "maxpool3s2_bwd: bad shape");
+    WU_REQUIRE(al16(dy) && al16(dx) && (lddy * esz) % 16 == 0 && (lddx * esz) % 16 == 0, "maxpool3s2_bwd: alignment");
+    WU_REQUIRE(gate_act == WU_ACT_NONE || (x && al16(x) && (ldx * esz) % 16 == 0), "maxpool3s2_bwd: gate needs x");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)N * H * W * (C / (16 / esz));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool3s2_bwd_kernel<T>, dim3(grid_cap(total)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)dy, lddy, argmax, (const T*)x, ldx, (T*)dx, lddx, N, H, W, Ho, Wo, C, gate_act));
+    WU_LAUNCH_CHECK("maxpool3s2_bwd");
+    return 0;
+}

@@ -14,11 +14,11 @@ LIB_PATH = os.path.join(_PKG, "lib", "libwu_kernels.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 OPT_CONV_V2, OPT_CONV_PERSISTENT, OPT_WGRAD_V2 = 0, 1, 2
-FAM_CONV_FWD, FAM_WGRAD, FAM_CONV_DGRAD, FAM_CONV_S2, FAM_WGRAD_S2 = 1, 2, 3, 4, 5
+FAM_CONV_FWD, FAM_WGRAD, FAM_CONV_DGRAD, FAM_CONV_S2, FAM_WGRAD_S2, FAM_CONV1X1 = 1, 2, 3, 4, 5, 6
 FAMILY_KERNEL = {1: "conv3x3_mfma_v2_kernel (forward + data-gradient convs; generic conv3x3_mfma_kernel for fp32 / narrow images)",
                  2: "conv3x3_wgrad_v2_kernel (generic conv3x3_wgrad_kernel for fp32 / narrow images)",
                  3: "conv3x3_mfma_kernel<T,1,true> (in-kernel gated dgrad; unused by the fused graph)",
-                 4: "conv3x3_mfma_kernel<T,2,false>", 5: "conv3x3_wgrad_kernel<T,2>"}
+                 4: "conv3x3_mfma_kernel<T,2,false>", 5: "conv3x3_wgrad_kernel<T,2>", 6: "conv1x1_mfma_kernel<T> (estimator)"}
 
 P, I, F, U64, SZ = c_void_p, c_int, c_float, c_uint64, c_size_t
 
@@ -58,6 +58,11 @@ SIGNATURES = {
     "wu_sumpool_bwd": (I, [P, P, I, I, I, I, I, I, P]),
     "wu_nhwc_to_nchw_f32": (I, [P, I, P, I, I, I, I, I, P]),
     "wu_nchw_f32_to_nhwc": (I, [P, P, I, I, I, I, I, I, P]),
+    "wu_conv1x1_fwd": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, I, I, I, P]),
+    "wu_stem7x7_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "wu_stem7x7_dgrad": (I, [P, I, P, P, I, I, I, I, I, P]),
+    "wu_maxpool3s2_fwd": (I, [P, I, P, I, P, I, I, I, I, I, P]),
+    "wu_maxpool3s2_bwd": (I, [P, I, P, P, I, P, I, I, I, I, I, I, I, P]),
     "wu_prof_begin": (I, [ctypes.c_uint, I]),
     "wu_prof_query": (I, [I, POINTER(c_int), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "wu_prof_end": (I, []),

@@ -1,0 +1,271 @@
+"""The estimator of the reference's GAN loop -- a frozen, eval-mode torchvision ResNet-101 (classifier.py:106-112,
+estimator.py:143-151; loaded as a pickle at t_cls_train.py:172-178) -- on this library's HIP kernels.
+
+The reference calls it four times per iteration (``estimator(rand_images)`` :424, ``estimator(images)`` :297 and :237,
+``estimator(fake_out)`` / ``estimator_(fake_out)`` :247-250) and differentiates the last call with respect to its INPUT:
+``g_loss_w`` flows through the estimator into the generator (:256,270,272).  The weights never train (:173-178 ``.eval()``,
+frozen parameters), so
+
+  * every BatchNorm is a per-channel affine, folded once into the preceding conv's weight and bias;
+  * only forward and DATA gradients exist: no weight gradients, no optimizer state;
+  * the whole network is ONE autograd node with a static kernel schedule (as wu/unet_graph.py does for the generator): each
+    data-gradient kernel hands its producer a gradient that is already gated by that producer's ReLU, the residual sums are
+    epilogue adds, and under ``torch.no_grad()`` (three of the four calls) nothing is kept.
+
+``ResNet101Estimator`` keeps torchvision's module tree NAMES (``conv1, bn1, layer1.0.conv1, ..., layer4.2.bn3, fc`` and the
+``downsample.0 / downsample.1`` pairs) as plain parameter / buffer holders, so ``load_state_dict`` accepts a torchvision
+ResNet-101 state-dict unchanged; torchvision itself is not needed.  The forward returns RAW outputs (what the scripts call
+``estimator_``; ``t_cls_train`` wraps it in ``nn.Softmax`` to get ``estimator``).
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _lib
+from . import kernels as K
+from .layout import dtype_code, empty_nhwc, nhwc_ld, precision_code, require_cuda, stream_ptr, torch_dtype
+
+RELU, NONE = K.ACT_RELU, K.ACT_NONE
+LAYERS = ((64, 3, 1), (128, 4, 2), (256, 23, 2), (512, 3, 2))     # torchvision resnet101: (planes, blocks, stride)
+EXPANSION = 4
+BN_EPS = 1e-5
+
+
+# ----------------------------------------------------------------------------------------------
+# launch helpers (C ABI: include/wu_kernels.h, "frozen ResNet-101 estimator")
+# ----------------------------------------------------------------------------------------------
+def conv1x1(x, w, bias, y, act=NONE, residual=None, egate=None, egate_act=NONE, in_stride=1, out_stride=1):
+    """y = act(w . x + bias + residual) * act'(egate): rows = the coarse grid (see wu_conv1x1_fwd)."""
+    n, cin, hin, win = x.shape
+    _, cout, hout, wout = y.shape
+    if in_stride == 2:
+        hc, wc = (hin - 1) // 2 + 1, (win - 1) // 2 + 1
+    elif out_stride == 2:
+        hc, wc = hin, win
+    else:
+        hc, wc = hin, win
+    rp, rld = (residual.data_ptr(), nhwc_ld(residual)) if residual is not None else (None, 0)
+    ep, eld = (egate.data_ptr(), nhwc_ld(egate)) if egate is not None else (None, 0)
+    _lib.call("wu_conv1x1_fwd", x.data_ptr(), nhwc_ld(x), w.data_ptr(), bias.data_ptr() if bias is not None else None, rp, rld,
+              y.data_ptr(), nhwc_ld(y), n, hc, wc, in_stride, hin, win, out_stride, hout, wout, cin, cout, act,
+              ep, eld, egate_act, dtype_code(x), stream_ptr())
+    return y
+
+
+def stem7x7(x_nchw, w, bias, y, act, code):
+    n, _, h, w_ = x_nchw.shape
+    _lib.call("wu_stem7x7_fwd", x_nchw.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), nhwc_ld(y),
+              n, h, w_, act, code, stream_ptr())
+    return y
+
+
+def stem7x7_dgrad(gy, w, dx_nchw, code, accumulate=False):
+    n, _, h, w_ = dx_nchw.shape
+    _lib.call("wu_stem7x7_dgrad", gy.data_ptr(), nhwc_ld(gy), w.data_ptr(), dx_nchw.data_ptr(), n, h, w_, 1 if accumulate else 0, code, stream_ptr())
+    return dx_nchw
+
+
+def maxpool3s2(x, y, argmax=None):
+    n, c, h, w = x.shape
+    _lib.call("wu_maxpool3s2_fwd", x.data_ptr(), nhwc_ld(x), y.data_ptr(), nhwc_ld(y), argmax.data_ptr() if argmax is not None else None,
+              n, h, w, c, dtype_code(x), stream_ptr())
+    return y
+
+
+def maxpool3s2_bwd(gy, argmax, x, dx, gate_act=NONE):
+    n, c, h, w = dx.shape
+    _lib.call("wu_maxpool3s2_bwd", gy.data_ptr(), nhwc_ld(gy), argmax.data_ptr(), x.data_ptr() if x is not None else None,
+              nhwc_ld(x) if x is not None else 0, dx.data_ptr(), nhwc_ld(dx), n, h, w, c, gate_act, dtype_code(gy), stream_ptr())
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter holders with torchvision's names
+# ----------------------------------------------------------------------------------------------
+class _ConvP(nn.Module):
+    def __init__(self, cout, cin, k):
+        super().__init__()
+        w = torch.empty(cout, cin, k, k)
+        nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")      # torchvision ResNet.__init__
+        self.weight = nn.Parameter(w, requires_grad=False)
+
+
+class _BNP(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(c), requires_grad=False)
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def affine(self):
+        """(scale, shift) of eval-mode nn.BatchNorm2d: y = x * scale + shift."""
+        scale = self.weight / torch.sqrt(self.running_var + BN_EPS)
+        return scale, self.bias - self.running_mean * scale
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1, self.bn1 = _ConvP(planes, inplanes, 1), _BNP(planes)
+        self.conv2, self.bn2 = _ConvP(planes, planes, 3), _BNP(planes)
+        self.conv3, self.bn3 = _ConvP(planes * EXPANSION, planes, 1), _BNP(planes * EXPANSION)
+        self.stride = stride
+        if downsample:
+            self.downsample = nn.Sequential(_ConvP(planes * EXPANSION, inplanes, 1), _BNP(planes * EXPANSION))
+        else:
+            self.downsample = None
+
+
+class ResNet101Estimator(nn.Module):
+    """Frozen eval-mode ResNet-101 -> (N, num_classes) raw outputs; input (N,3,H,W) fp32 NCHW with H, W >= 32."""
+
+    def __init__(self, num_classes=5, precision="bf16", layers=LAYERS):
+        super().__init__()
+        self.layers_cfg = tuple(layers)
+        self.conv1, self.bn1 = _ConvP(64, 3, 7), _BNP(64)
+        inplanes = 64
+        for li, (planes, blocks, stride) in enumerate(layers, start=1):
+            mods = []
+            for b in range(blocks):
+                s = stride if b == 0 else 1
+                mods.append(_Bottleneck(inplanes, planes, s, b == 0 and (s != 1 or inplanes != planes * EXPANSION)))
+                inplanes = planes * EXPANSION
+            setattr(self, f"layer{li}", nn.Sequential(*mods))
+        self.fc = nn.Linear(inplanes, num_classes)
+        for p in self.parameters():
+            p.requires_grad_(False)
+        precision_code(precision)
+        self.precision = precision
+        self._plan = None
+        self._plan_key = None
+        self.eval()
+
+    def train(self, mode=True):
+        # the reference keeps the estimator in eval mode for good (t_cls_train.py:173,178): BatchNorm folding relies on it
+        return super().train(False)
+
+    # ---- folded / packed operands, rebuilt when a tensor of the state changes ----
+    def _state_key(self):
+        ts = list(self.parameters()) + list(self.buffers())
+        return (self.precision,) + tuple((t.data_ptr(), t._version) for t in ts)
+
+    def plan(self):
+        key = self._state_key()
+        if key == self._plan_key:
+            return self._plan
+        code = precision_code(self.precision)
+        dt = torch_dtype(code)
+        with torch.no_grad():
+            def fold(conv, bn):
+                scale, shift = bn.affine()
+                return (conv.weight * scale.view(-1, 1, 1, 1)).float().contiguous(), shift.float().contiguous()
+
+            def pw(conv, bn):
+                w, b = fold(conv, bn)
+                w2 = w.view(w.shape[0], w.shape[1])
+                return {"w": w2.to(dt).contiguous(), "wt": w2.t().to(dt).contiguous(), "b": b}
+
+            def c3(conv, bn):
+                w, b = fold(conv, bn)
+                wf, wd = K.pack_conv3x3(w, code)
+                return {"w": wf, "wd": wd, "b": b}
+            ws, bs = fold(self.conv1, self.bn1)
+            plan = {"stem_w": ws, "stem_b": bs, "blocks": []}
+            for li in range(1, len(self.layers_cfg) + 1):
+                for blk in getattr(self, f"layer{li}"):
+                    plan["blocks"].append({"c1": pw(blk.conv1, blk.bn1), "c2": c3(blk.conv2, blk.bn2), "c3": pw(blk.conv3, blk.bn3),
+                                           "ds": pw(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None,
+                                           "stride": blk.stride, "planes": blk.conv1.weight.shape[0]})
+        self._plan, self._plan_key = plan, key
+        return plan
+
+    def forward(self, x):
+        require_cuda(x, "ResNet101Estimator")
+        if x.shape[2] < 32 or x.shape[3] < 32:
+            raise ValueError(f"ResNet101Estimator: input {tuple(x.shape)} is smaller than the network's stride (32)")
+        feat = ResNetFn.apply(x, self.plan(), precision_code(self.precision))       # (N, 2048) fp32: global average pool
+        return torch.nn.functional.linear(feat, self.fc.weight, self.fc.bias)
+
+
+# ----------------------------------------------------------------------------------------------
+# the network body as one autograd node
+# ----------------------------------------------------------------------------------------------
+def _half(v, s):
+    return (v - 1) // s + 1
+
+
+class ResNetFn(Function):
+    @staticmethod
+    def forward(ctx, x, plan, code):
+        dt, dev = torch_dtype(code), x.device
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        n, _, h, w = x.shape
+        keep = ctx.needs_input_grad[0]
+
+        def new(c, hh, ww):
+            return empty_nhwc(n, c, hh, ww, dt, dev)
+        h1, w1 = _half(h, 2), _half(w, 2)
+        stem = stem7x7(x, plan["stem_w"], plan["stem_b"], new(64, h1, w1), RELU, code)        # conv1 + bn1 + relu
+        h2, w2 = _half(h1, 2), _half(w1, 2)
+        amax = torch.empty(n * h2 * w2 * 64, dtype=torch.uint8, device=dev) if keep else None
+        cur = maxpool3s2(stem, new(64, h2, w2), amax)                                          # maxpool
+        saved = []
+        hh, ww = h2, w2
+        for blk in plan["blocks"]:
+            s, planes = blk["stride"], blk["planes"]
+            a = conv1x1(cur, blk["c1"]["w"], blk["c1"]["b"], new(planes, hh, ww), RELU)        # conv1 + bn1 + relu
+            ho, wo = _half(hh, s), _half(ww, s)
+            b = K.conv3x3(a, blk["c2"]["w"], blk["c2"]["b"], new(planes, ho, wo), s, RELU)      # conv2 (stride here) + bn2 + relu
+            if blk["ds"] is not None:                                                           # downsample: conv1x1 stride s + bn
+                idn = conv1x1(cur, blk["ds"]["w"], blk["ds"]["b"], new(planes * EXPANSION, ho, wo), NONE, in_stride=s)
+            else:
+                idn = cur
+            out = conv1x1(b, blk["c3"]["w"], blk["c3"]["b"], new(planes * EXPANSION, ho, wo), RELU, residual=idn)   # conv3 + bn3 + add + relu
+            if keep:
+                saved.append((cur, a, b, out))
+            cur, hh, ww = out, ho, wo
+        feat = torch.empty((n, cur.shape[1]), dtype=torch.float32, device=dev)
+        _lib.call("wu_sumpool_fwd", cur.data_ptr(), nhwc_ld(cur), feat.data_ptr(), n, hh, ww, cur.shape[1], code, stream_ptr())
+        feat.mul_(1.0 / (hh * ww))                                                              # adaptive_avg_pool2d(1)
+        if keep:
+            ctx.plan, ctx.code, ctx.saved, ctx.stem, ctx.amax, ctx.xshape = plan, code, saved, stem, amax, tuple(x.shape)
+        return feat
+
+    @staticmethod
+    def backward(ctx, gfeat):
+        plan, code, saved, stem, amax = ctx.plan, ctx.code, ctx.saved, ctx.stem, ctx.amax
+        dt, dev = torch_dtype(code), gfeat.device
+        n, _, h, w = ctx.xshape
+
+        def new(c, hh, ww):
+            return empty_nhwc(n, c, hh, ww, dt, dev)
+        last = saved[-1][3]
+        _, c, hh, ww = last.shape
+        g = new(c, hh, ww)
+        gf = (gfeat.float() * (1.0 / (hh * ww))).contiguous()
+        _lib.call("wu_sumpool_bwd", gf.data_ptr(), g.data_ptr(), nhwc_ld(g), n, hh, ww, c, code, stream_ptr())
+        g = K.act_gate(g, last, RELU, out=g)                        # gradient wrt the last block's pre-ReLU sum
+        for blk, (xin, a, b, out) in zip(reversed(plan["blocks"]), reversed(saved)):
+            s, planes = blk["stride"], blk["planes"]
+            # g: gradient of this block's output, already gated by its final ReLU
+            gb = conv1x1(g, blk["c3"]["wt"], None, new(planes, b.shape[2], b.shape[3]), NONE, egate=b, egate_act=RELU)
+            ga = new(planes, a.shape[2], a.shape[3])
+            if s == 1:
+                K.conv3x3(gb, blk["c2"]["wd"], None, ga, egate=a, egate_act=RELU)
+            else:
+                K.conv3x3_s2_dgrad(gb, blk["c2"]["wd"], ga, egate=a, egate_act=RELU)
+            if blk["ds"] is not None:
+                skip = conv1x1(g, blk["ds"]["wt"], None, new(xin.shape[1], xin.shape[2], xin.shape[3]), NONE, out_stride=s)
+            else:
+                skip = g
+            # gradient wrt the block input = conv1 path + identity path; gated by the ReLU that produced the input (every block
+            # input is a ReLU output; for the first block it is max-pool(ReLU(stem)): x > 0 there implies the routed stem element > 0)
+            g = conv1x1(ga, blk["c1"]["wt"], None, new(xin.shape[1], xin.shape[2], xin.shape[3]), NONE, residual=skip,
+                        egate=xin, egate_act=RELU)
+        gstem = maxpool3s2_bwd(g, amax, stem, new(64, stem.shape[2], stem.shape[3]), gate_act=RELU)
+        dx = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
+        stem7x7_dgrad(gstem, plan["stem_w"], dx, code)
+        return dx, None, None
