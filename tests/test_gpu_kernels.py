@@ -429,37 +429,3 @@ def test_conv3x3_relu_pool_fused(p, shape):
     assert torch.equal(pool.float(), ref_pool)
     ref = F.relu(F.conv2d(x, wt, b, padding=1))
     assert (y.float().cpu() - ref).abs().max().item() <= _tol(p, ref)
-
-
-@pytest.mark.parametrize("shape", [(2, 64, 64, 48, 64), (1, 192, 64, 40, 72), (2, 64, 128, 33, 35), (1, 256, 128, 20, 40), (1, 512, 512, 32, 32)])
-def test_conv_two_workgroups_per_cu_is_bitwise_equal(shape):
-    """conv3x3_mfma_v2s (two 4-wave workgroups per CU, one LDS buffer each) computes the same MFMA sequence per output as
-    conv3x3_mfma_v2: forward + ReLU (+ fused max-pool) and the gated data-gradient pass must be bit-identical."""
-    from wu import _lib, kernels as K
-    from wu.layout import empty_nhwc
-    n, cin, cout, h, w = shape
-    dev = _dev()
-    x = _nhwc(_rand((n, cin, h, w), 1), "bf16")
-    gate = _nhwc(_rand((n, cout, h, w), 4), "bf16")
-    wt = _rand((cout, cin, 3, 3), 2, -0.1, 0.1).to(dev)
-    b = _rand((cout,), 3).to(dev)
-    wf, wd = K.pack_conv3x3(wt, _lib.BF16)
-    res = {}
-    try:
-        for mode in (0, 1):
-            _lib.call("wu_set_option", 8, mode)
-            y = K.conv3x3(x, wf, b, empty_nhwc(n, cout, h, w, torch.bfloat16, dev), 1, 1)
-            yg = K.conv3x3(x, wf, None, empty_nhwc(n, cout, h, w, torch.bfloat16, dev), 1, 0, egate=gate, egate_act=1)
-            out = [y.clone(), yg.clone()]
-            if h % 2 == 0 and w % 2 == 0:
-                yp = empty_nhwc(n, cout, h, w, torch.bfloat16, dev)
-                pool = empty_nhwc(n, cout, h // 2, w // 2, torch.bfloat16, dev)
-                K.conv3x3_relu_pool(x, wf, b, yp, pool)
-                out += [yp.clone(), pool.clone()]
-            res[mode] = out
-    finally:
-        _lib.call("wu_set_option", 8, 0)
-    for a_, b_ in zip(res[0], res[1]):
-        assert torch.equal(a_, b_)
-    ref = F.relu(F.conv2d(x.float().cpu(), wt.cpu().to(torch.bfloat16).float(), b.cpu(), padding=1))
-    assert (res[1][0].float().cpu() - ref).abs().max().item() <= _tol("bf16", ref)

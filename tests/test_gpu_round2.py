@@ -48,9 +48,18 @@ def _cos_rel(a, b):
 def test_bf16_gradients_vs_emulating_oracle(shape, train):
     """HIP bf16 forward + all 36 parameter gradients against oracle.cunet_forward(emulate_bf16=True): the reference's graph with
     every tensor the kernels park in HBM as bf16 rounded at that point (and its gradient likewise, through autograd).  What is
-    left is fp32 summation order.  Tolerances: forward max-abs <= 1e-2 (a handful of last-bit bf16 flips propagated to the tanh
-    output), every gradient cosine >= 0.999 and relative L2 error <= 4e-2.  Against the un-emulated fp32 oracle the same
-    gradients sit at cosine 0.95-0.99 (printed): that gap is the precision mode, not the kernels."""
+    left between the two is fp32 summation order.
+
+    Finding (round 2): that is NOT a small difference for the deep layers.  Two CPU emulations of the same bf16 graph that differ
+    only in the order their convs visit the input channels (``sum_order``) agree to cosine 0.9998 on dconv_up1.*, but only
+    0.96-0.98 from dconv_up2 inwards: the instance-norm backward removes the mean / x-hat components of a gradient dominated by
+    those components, so last-bit bf16 flips of that gradient are amplified.  The bf16 gradient is therefore pinned as:
+      * forward max-abs vs the emulation <= 1e-2 (and <= 5e-2 vs the fp32 oracle, north_star's tolerance);
+      * the layers downstream of the last AdaIN (dconv_up1.*, conv_last.*), which no amplification has touched: cosine >= 0.999,
+        relative L2 error <= 5e-2;
+      * every one of the 36 gradients: the HIP result is no further from the emulation than 2x the distance between the two
+        emulations (+ 2e-3): the kernels sit inside the spread of the precision mode itself.
+    """
     from wu import functional as WF
     n, h, w = shape
     nc, seed = 5, 13
@@ -68,33 +77,33 @@ def test_bf16_gradients_vs_emulating_oracle(shape, train):
     out = net(xd, c.to(DEV))
     torch.mean(torch.abs(out - xd)).backward()
     res = {}
-    for emu in (True, False):
+    for tag, emu, order in (("emu", True, None), ("emu2", True, 1), ("fp32", False, None)):
         p = {k: v.clone().requires_grad_(True) for k, v in O.make_cunet_params(nc, seed).items()}
-        ref = O.cunet_forward(p, x, c, masks, emulate_bf16=emu)
+        ref = O.cunet_forward(p, x, c, masks, emulate_bf16=emu, sum_order=order)
         O.bench_loss(ref, x).backward()
-        res[emu] = (ref.detach(), p)
-    err = (out.detach().cpu() - res[True][0]).abs().max().item()
-    err32 = (out.detach().cpu() - res[False][0]).abs().max().item()
-    print(f"bf16 {shape} train={train}: forward max-abs vs emulating oracle {err:.3e}, vs fp32 oracle {err32:.3e}")
+        res[tag] = (ref.detach(), p)
+    err = (out.detach().cpu() - res["emu"][0]).abs().max().item()
+    err32 = (out.detach().cpu() - res["fp32"][0]).abs().max().item()
+    err_ee = (res["emu"][0] - res["emu2"][0]).abs().max().item()
+    print(f"bf16 {shape} train={train}: forward max-abs vs emulating oracle {err:.3e}, vs fp32 oracle {err32:.3e}; emulation vs re-ordered emulation {err_ee:.3e}")
     assert err <= 1e-2 and err32 <= FWD_TOL["bf16"]
-    worst = (1.0, 0.0)
-    checked = 0
-    bad = []
+    checked, bad = 0, []
     for k, prm in net.named_parameters():
         if k.endswith("emb.weight"):
             assert prm.grad is None
             continue
-        cos, rel = _cos_rel(prm.grad, res[True][1][k].grad)
-        cos32, _ = _cos_rel(prm.grad, res[False][1][k].grad)
-        cos_oo, _ = _cos_rel(res[True][1][k].grad, res[False][1][k].grad)
-        print(f"   {k:24s} vs emulated: cos {cos:.6f} rel {rel:.4f}   | vs fp32 oracle: cos {cos32:.5f}   | emulated vs fp32 oracle: cos {cos_oo:.5f}")
-        worst = (min(worst[0], cos), max(worst[1], rel))
+        cos, rel = _cos_rel(prm.grad, res["emu"][1][k].grad)
+        cos2, _ = _cos_rel(prm.grad, res["emu2"][1][k].grad)
+        cos_ee, _ = _cos_rel(res["emu"][1][k].grad, res["emu2"][1][k].grad)
+        cos32, _ = _cos_rel(prm.grad, res["fp32"][1][k].grad)
+        print(f"   {k:24s} HIP vs emulation: cos {cos:.6f} (rel {rel:.4f}), vs re-ordered emulation {cos2:.6f} | emulation vs re-ordered emulation: {cos_ee:.6f} | HIP vs fp32 oracle: {cos32:.5f}")
         checked += 1
-        if not (cos >= 0.999 and rel <= 4e-2):
-            bad.append(f"{k}: cos {cos:.6f} rel {rel:.4f}")
-    assert not bad, "vs the bf16-emulating oracle: " + "; ".join(bad)
+        if k.startswith(("dconv_up1", "conv_last")) and not (cos >= 0.999 and rel <= 5e-2):
+            bad.append(f"{k}: cos {cos:.6f} rel {rel:.4f} (no AdaIN backward upstream: must be tight)")
+        if 1.0 - min(cos, cos2) > 2.0 * (1.0 - cos_ee) + 2e-3:
+            bad.append(f"{k}: HIP-to-emulation distance {1 - min(cos, cos2):.4f} exceeds 2x the emulation-to-emulation distance {1 - cos_ee:.4f}")
+    assert not bad, "; ".join(bad)
     assert checked == 36
-    print(f"   worst: cos {worst[0]:.6f} rel {worst[1]:.4f}")
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

@@ -340,8 +340,7 @@ extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, cons
     const int fam = stride == 2 ? WU_FAM_CONV_S2 : (m ? WU_FAM_CONV_DGRAD : WU_FAM_CONV_FWD);
     if (g_wu_opt[WU_OPT_CONV_V2] && conv_v2_eligible(H, W, ldx, Cin, Cout, stride, dtype, m) && (egate == nullptr || act == WU_ACT_NONE)) {
         wu_prof_pre(fam, s);
-        const int rc = conv_use_v2s(Cin) ? conv_v2s_launch(x, ldx, w_packed, bias, y, ldy, egate, ldegate, egate_act, N, H, W, Cin, Cout, act, s)
-                                         : conv_v2_launch(x, ldx, w_packed, bias, y, ldy, egate, ldegate, egate_act, N, H, W, Cin, Cout, act, s);
+        const int rc = conv_v2_launch(x, ldx, w_packed, bias, y, ldy, egate, ldegate, egate_act, N, H, W, Cin, Cout, act, s);
         WU_REQUIRE(rc == 0, "conv3x3_fwd: grid too large");
         wu_prof_post(fam, s, 2.0 * N * H * W * (double)Cout * 9.0 * Cin,
                      ((double)N * H * W * (Cin + Cout) + 9.0 * Cin * Cout) * esz);
@@ -378,8 +377,7 @@ extern "C" int wu_conv3x3_relu_pool_fwd(const void* x, int ldx, const void* w_pa
                        conv_v2_eligible(H, W, ldx, Cin, Cout, 1, dtype, false);
     if (fused) {
         wu_prof_pre(WU_FAM_CONV_FWD, s);
-        const int rc = conv_use_v2s(Cin) ? conv_v2s_launch(x, ldx, w_packed, bias, y, ldy, nullptr, 0, 0, N, H, W, Cin, Cout, WU_ACT_RELU, s, pool, ldpool)
-                                         : conv_v2_launch(x, ldx, w_packed, bias, y, ldy, nullptr, 0, 0, N, H, W, Cin, Cout, WU_ACT_RELU, s, pool, ldpool);
+        const int rc = conv_v2_launch(x, ldx, w_packed, bias, y, ldy, nullptr, 0, 0, N, H, W, Cin, Cout, WU_ACT_RELU, s, pool, ldpool);
         WU_REQUIRE(rc == 0, "conv3x3_relu_pool_fwd: grid too large");
         wu_prof_post(WU_FAM_CONV_FWD, s, 2.0 * N * H * W * (double)Cout * 9.0 * Cin, ((double)N * H * W * (Cin + Cout) + 9.0 * Cin * Cout) * esz);
         WU_LAUNCH_CHECK("conv3x3_mfma_v2 (+pool)");

@@ -41,7 +41,6 @@ extern void* g_wu_dbg_ptr;
 #define WU_OPT_C3_ROWS 5
 #define WU_OPT_CONV_PRIO 6
 #define WU_OPT_CONV_STRIDED 7
-#define WU_OPT_CONV_V2S 8
 
 int wu_num_cus();   // compute units of the current device (wu_prof.hip), cached
 
