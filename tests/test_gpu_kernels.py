@@ -265,7 +265,7 @@ def _adain_upcat_ref(x, c_std, c_mean, skip, eps, mask):
 
 
 @pytest.mark.parametrize("p", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 128, 8, 8, 64), (1, 256, 4, 6, 128), (2, 64, 16, 16, 64)])
+@pytest.mark.parametrize("shape", [(2, 128, 8, 8, 64), (1, 256, 4, 6, 128), (2, 64, 16, 16, 64), (1, 64, 5, 7, 64), (2, 128, 40, 72, 64)])
 @pytest.mark.parametrize("train", [False, True])
 def test_adain_upcat(p, shape, train):
     """AdaIN (utils.py:41-51) -> bilinear x2 align_corners (cunet.py:26) -> Dropout(0.3) -> cat, fused; forward
@@ -429,3 +429,34 @@ def test_conv3x3_relu_pool_fused(p, shape):
     assert torch.equal(pool.float(), ref_pool)
     ref = F.relu(F.conv2d(x, wt, b, padding=1))
     assert (y.float().cpu() - ref).abs().max().item() <= _tol(p, ref)
+
+
+@pytest.mark.parametrize("p", DTYPES)
+def test_adain_upcat_bwd_marching_vs_gather(p):
+    """The two formulations of the fused AdaIN / bilinear / dropout backward (16-tap gather per low-res pixel; separable
+    "marching" over high-res rows, two low-res columns per thread) compute the same sums in a different order."""
+    from wu import _lib, functional as WF, kernels as K
+    from wu.layout import empty_nhwc
+    n, c, h, w, cs, seed = 2, 128, 24, 40, 64, 99
+    x = _nhwc(_round(_rand((n, c, h, w), 81, -1, 2), p), p)
+    g = _nhwc(_round(_rand((n, c + cs, 2 * h, 2 * w), 82), p), p)
+    ystd = _rand((n, c), 83, 0.5, 1.5).to(_dev())
+    ymean = _rand((n, c), 84).to(_dev())
+    stats = K.adain_stats(x, 1e-5)
+    cat = empty_nhwc(n, c + cs, 2 * h, 2 * w, _tdt(p), _dev())
+    mb = K.adain_upcat(x, stats, ystd, ymean, cat, 0.3, seed, True)
+    res = {}
+    try:
+        for mode in (0, 1):
+            _lib.call("wu_set_option", 8, mode)
+            for bits in (mb, None):
+                dx = empty_nhwc(n, c, h, w, _tdt(p), _dev())
+                ds, dm = K.adain_upcat_bwd(g, x, stats, ystd, dx, 0.3, seed, bits, 1)
+                res[(mode, bits is None)] = (dx.float().clone(), ds.clone(), dm.clone())
+    finally:
+        _lib.call("wu_set_option", 8, 1)
+    for k in ((1, False), (1, True), (0, True)):
+        for a_, b_ in zip(res[k], res[(0, False)]):
+            scale = max(1.0, b_.abs().max().item())
+            assert (a_ - b_).abs().max().item() <= (1e-4 if p == "fp32" else 2e-2) * scale, k
+    assert torch.equal(res[(1, False)][0], res[(1, True)][0])        # stored keep-bits == regenerated mask

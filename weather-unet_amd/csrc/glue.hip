@@ -404,6 +404,163 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_gather_kernel(
     block_reduce_2x64<PP>(red, tid, sums + (((size_t)n * C + cg * 64) * splits + blockIdx.y) * 2, splits * 2);
 }
 
+// backward stage A, second formulation ("marching"): a thread owns TWO adjacent low-resolution columns of one 16-byte channel chunk and
+// walks down the high-resolution rows of its strip.  Per high-res row it loads the 6 columns that touch its two low-res columns
+// once (the 16-tap gather above loads 16 chunks per low-res pixel, this one 3), reduces them horizontally with row-independent
+// weights, and adds the result into the (at most two) low-res rows that row interpolates from -- the bilinear x2 operator is
+// separable, so its transpose is too.  Same sums, same parked g', same per-(n,c) statistics; the partial-sum slot of a workgroup is
+// its (column tile, row strip) index.
+template <typename T>
+__global__ __launch_bounds__(256) void adain_upcat_bwd_march_kernel(
+    const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx, const float* __restrict__ stats,
+    T* __restrict__ gtmp, float* __restrict__ sums, int H, int W, int C, int rows_per_strip, int col_tiles,
+    float sy, float sx, uint32_t thr, float keep_scale, uint64_t seed, const uint8_t* __restrict__ mbits) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    constexpr int LP = 64 / E, PP = 256 / LP;          // lanes per pixel (64 channels), column pairs per workgroup
+    __shared__ float red[PP][64][2];
+    __shared__ uint4 lut[E == 8 ? 256 : 1];
+    const int tid = threadIdx.x;
+    if (E == 8 && thr < 0x10000u && mbits) {
+        uint32_t m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = ((tid >> (2 * k)) & 1 ? 0x0000ffffu : 0u) | ((tid >> (2 * k + 1)) & 1 ? 0xffff0000u : 0u);
+        lut[tid] = make_uint4(m[0], m[1], m[2], m[3]);
+        __syncthreads();
+    }
+    const int cg = blockIdx.x, n = blockIdx.z;
+    const int ctile = blockIdx.y % col_tiles, strip = blockIdx.y / col_tiles;
+    const int cl = tid % LP, pl = tid / LP;
+    const int c0 = cg * 64 + cl * E;
+    const int cpp = C / E, chunk = c0 / E;
+    const int H2 = 2 * H, W2 = 2 * W, HW = H * W;
+    const int xa = 2 * (ctile * PP + pl), xb = xa + 1;               // this thread's two low-res columns
+    const bool va = xa < W, vb = xb < W;
+    const int y0 = strip * rows_per_strip, y1 = min(H, y0 + rows_per_strip);
+    float s1[E], s2[E], st[2 * E];
+    ldf<2 * E>(stats + 2 * (n * C + c0), st);
+#pragma unroll
+    for (int e = 0; e < E; ++e) s1[e] = s2[e] = 0.f;
+    // the 6 high-res columns 2*xa - 1 .. 2*xa + 4 and their weights towards xa (first four) and xb (last four)
+    int jx[6];
+    float wa[6], wb[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int j = 2 * xa - 1 + k;
+        const int jc = min(max(j, 0), W2 - 1);
+        const Lerp lx = src_index(jc, sx, W);
+        const bool in = j == jc;
+        wa[k] = (in && k < 4) ? ((lx.i0 == xa ? lx.l0 : 0.f) + (lx.i1 == xa ? lx.l1 : 0.f)) : 0.f;
+        wb[k] = (in && k >= 2) ? ((lx.i0 == xb ? lx.l0 : 0.f) + (lx.i1 == xb ? lx.l1 : 0.f)) : 0.f;
+        jx[k] = jc;
+    }
+    // two pending low-res rows per column: acc?0 = row `cur`, acc?1 = row `cur + 1`
+    float a0[E], a1[E], b0[E], b1[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) a0[e] = a1[e] = b0[e] = b1[e] = 0.f;
+    const int r_begin = max(0, 2 * y0 - 1), r_end = min(H2 - 1, 2 * y1);           // rows that can touch [y0, y1)
+    int cur = src_index(r_begin, sy, H).i0;
+
+    auto emit = [&](int yy, const float* ga, const float* gb) __attribute__((always_inline)) {
+        if (yy < y0 || yy >= y1) return;
+        const size_t p = (size_t)n * HW + (size_t)yy * W;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int xx = side ? xb : xa;
+            if (!(side ? vb : va)) continue;
+            const float* g = side ? gb : ga;
+            float gs[E], xv[E];
+            unpack16<T>(*(const uint4*)(x + (p + xx) * ldx + c0), xv);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                gs[e] = thr < 0x10000u ? g[e] * keep_scale : g[e];
+                s1[e] += gs[e];
+                s2[e] += gs[e] * ((xv[e] - st[2 * e]) * st[2 * e + 1]);
+            }
+            *(uint4*)(gtmp + (p + xx) * C + c0) = pack16<T>(gs);
+        }
+    };
+
+    if (va) {
+        // the loads of row r + 1 are issued before row r is reduced: one memory round trip per row pair is always in flight
+        uint4 dvn[6];
+        uint32_t bvn[6];
+        auto load_row = [&](int r) __attribute__((always_inline)) {
+            const size_t rp = (size_t)(n * H2 + r) * W2;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                dvn[k] = *(const uint4*)(dy + (rp + jx[k]) * lddy + c0);
+                bvn[k] = (thr < 0x10000u && mbits) ? mbits[(rp + jx[k]) * cpp + chunk] : 0u;
+            }
+        };
+        load_row(r_begin);
+        for (int r = r_begin; r <= r_end; ++r) {
+            const Lerp ly = src_index(r, sy, H);
+            uint4 dv[6];
+            uint32_t bv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { dv[k] = dvn[k]; bv[k] = bvn[k]; }
+            load_row(min(r + 1, r_end));
+            // retire the rows no later high-res row can touch
+            while (cur < ly.i0) {
+                emit(cur, a0, b0);
+#pragma unroll
+                for (int e = 0; e < E; ++e) { a0[e] = a1[e]; b0[e] = b1[e]; a1[e] = 0.f; b1[e] = 0.f; }
+                ++cur;
+            }
+            const size_t rowpix = (size_t)(n * H2 + r) * W2;
+            float ta[E], tb[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) ta[e] = tb[e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                float d[E];
+                if (thr < 0x10000u) {
+                    if (mbits && E == 8) {
+                        const uint4 mk = lut[bv[k] & 255u];
+                        unpack16<T>(make_uint4(dv[k].x & mk.x, dv[k].y & mk.y, dv[k].z & mk.z, dv[k].w & mk.w), d);
+                    } else if (mbits) {
+                        unpack16<T>(dv[k], d);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) d[e] = ((bv[k] >> e) & 1u) ? d[e] : 0.f;
+                    } else {
+                        bool keep[E];
+                        keep_bits<E>(seed, (uint64_t)(rowpix + jx[k]) * C + c0, thr, keep);
+                        unpack16<T>(dv[k], d);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) d[e] = keep[e] ? d[e] : 0.f;
+                    }
+                } else {
+                    unpack16<T>(dv[k], d);
+                }
+                if (k < 4) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) ta[e] = fmaf(wa[k], d[e], ta[e]);
+                }
+                if (k >= 2) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) tb[e] = fmaf(wb[k], d[e], tb[e]);
+                }
+            }
+            // vertical: this row interpolates from low-res rows i0 (weight l0) and i1 (weight l1; i1 == i0 on the last row)
+            const float l1w = ly.i1 != ly.i0 ? ly.l1 : 0.f, l0w = ly.i1 != ly.i0 ? ly.l0 : ly.l0 + ly.l1;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                a0[e] = fmaf(l0w, ta[e], a0[e]); b0[e] = fmaf(l0w, tb[e], b0[e]);
+                a1[e] = fmaf(l1w, ta[e], a1[e]); b1[e] = fmaf(l1w, tb[e], b1[e]);
+            }
+        }
+        emit(cur, a0, b0);
+        emit(cur + 1, a1, b1);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        red[pl][cl * E + e][0] = s1[e];
+        red[pl][cl * E + e][1] = s2[e];
+    }
+    const int splits = gridDim.y;
+    block_reduce_2x64<PP>(red, tid, sums + (((size_t)n * C + cg * 64) * splits + blockIdx.y) * 2, splits * 2);
+}
+
 // fold the per-split partials in fixed order: sums_final[n][c][2]
 __global__ void fold_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int NC2, int splits) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -662,16 +819,32 @@ extern "C" int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int l
     hipStream_t s = (hipStream_t)stream;
     const float sy = (float)(H - 1) / (float)(2 * H - 1), sx = (float)(W - 1) / (float)(2 * W - 1);
     const int HW = H * W;
-    int splits = cdiv(2048, N * (C / 64));
-    const int pp = 256 / (64 / (16 / esz));
-    if (splits > cdiv(HW, pp)) splits = cdiv(HW, pp);
-    if (splits > kMaxSplits) splits = kMaxSplits;
-    if (splits < 1) splits = 1;
-    const long long total = (long long)N * HW * (C / (16 / esz));
+    const int pp = 256 / (64 / (16 / esz));       // pixels (gather) / column pairs (march) per workgroup
     float* partials = sums + (size_t)N * C * 2;
+    int splits;
+    // marching formulation: workgroup = (64 channels, 2*pp low-res columns, a strip of rows); its partial-sum slot = (column tile, strip)
+    const int col_tiles = cdiv(W, 2 * pp);
+    const bool march = g_wu_opt[WU_OPT_ADAIN_BWD_MARCH] && col_tiles <= kMaxSplits;
+    if (march) {
+        int strips = kMaxSplits / col_tiles;
+        const int want = cdiv(2048, N * (C / 64) * col_tiles);      // enough workgroups to fill the chip
+        if (strips > want) strips = want;
+        if (strips > cdiv(H, 4)) strips = cdiv(H, 4);               // at least 4 low-res rows per strip (each strip re-reads a 1-row halo)
+        if (strips < 1) strips = 1;
+        const int rows_per_strip = cdiv(H, strips);
+        strips = cdiv(H, rows_per_strip);
+        splits = col_tiles * strips;
+        DISPATCH_T(dtype, hipLaunchKernelGGL(adain_upcat_bwd_march_kernel<T>, dim3(C / 64, splits, N), dim3(256), 0, s, (const T*)dy, lddy, (const T*)x, ldx,
+                                             stats, (T*)gtmp, partials, H, W, C, rows_per_strip, col_tiles, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), seed, mask_bits));
+    } else {
+        splits = cdiv(2048, N * (C / 64));
+        if (splits > cdiv(HW, pp)) splits = cdiv(HW, pp);
+        if (splits > kMaxSplits) splits = kMaxSplits;
+        if (splits < 1) splits = 1;
+        DISPATCH_T(dtype, hipLaunchKernelGGL(adain_upcat_bwd_gather_kernel<T>, dim3(C / 64, splits, N), dim3(256), 0, s, (const T*)dy, lddy, (const T*)x, ldx,
+                                             stats, (T*)gtmp, partials, H, W, C, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), seed, mask_bits));
+    }
     DISPATCH_T(dtype, {
-        hipLaunchKernelGGL(adain_upcat_bwd_gather_kernel<T>, dim3(C / 64, splits, N), dim3(256), 0, s, (const T*)dy, lddy, (const T*)x, ldx,
-                           stats, (T*)gtmp, partials, H, W, C, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), seed, mask_bits);
         hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(N * C * 2, 256)), dim3(256), 0, s, partials, sums, N * C * 2, splits);
         hipLaunchKernelGGL(adain_upcat_bwd_apply_kernel<T>, dim3(grid_for((long long)HW * (C / (16 / esz)), 256, 1024), N), dim3(256), 0, s, (const T*)gtmp, sums, (const T*)x, ldx, stats, y_std,
                            (T*)dx, lddx, d_y_std, d_y_mean, N, HW, C, x_gate_act);
