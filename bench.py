@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--fwd-only", action="store_true", help="inference forward (eval mode) instead of the training step")
     ap.add_argument("--graph", action="store_true", help="with --fwd-only: replay a hipGraph-captured forward (configs[4])")
     ap.add_argument("--force-ddp", action="store_true", help="initialise RCCL and use the bucketed reducer even with one rank (test hook)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="kernel-variant switch for A/B runs (wu_set_option; defaults are the production choices)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only (gloo, no GPU): every rank joins, rank 0 prints {\"launch_check\": world}; "
                          "exercises the --gpus N self-launch path on a CPU box")
@@ -125,6 +127,9 @@ def main():
     from wu import _lib
     from wu.ddp import GradBucketReducer, ready_order
 
+    for kv in a.opt:
+        k, v = kv.split("=")
+        _lib.call("wu_set_option", int(k), int(v))
     torch.manual_seed(0)                       # same random-init weights on every rank
     net = cunet.Conditional_UNet(5, precision=a.precision).to(dev)
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)      # a different synthetic shard per rank

@@ -244,6 +244,25 @@ int wu_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* argmax,
 int wu_maxpool3s2_bwd(const void* dy, int lddy, const uint8_t* argmax, const void* x, int ldx, void* dx, int lddx,
                       int N, int H, int W, int C, int gate_act, int dtype, void* stream);
 
+/* ---- input pipeline (t_cls_train.py:81-108: the torchvision / PIL transforms every training image goes through) ----------
+ * A batch of decoded RGB images lives in one uint8 buffer `src`; image n starts at byte geo[n].src_off, is src_h x src_w pixels
+ * with a row stride of src_ld pixels.  `geo` is an array of N records of wu_image_geo_bytes() (= 72) bytes:
+ *     int64 src_off; int32 src_h, src_w, src_ld, crop_top, crop_left, crop_h, crop_w, flip, rot[6], do_rot, pad;
+ * The crop window is resized to S x S with Pillow's two-pass fixed-point bilinear resample (transforms.Resize: the window is the
+ * whole image; RandomResizedCrop: the drawn box); rot[] are the 16.16 fixed-point coefficients of Image.rotate(angle, NEAREST)
+ * (libImaging/Geometry.c affine_fixed) -- for the S x S image when rot_first == 0 (Resize -> RandomRotation, :96-97), for the
+ * source image when rot_first != 0 (RandomRotation -> RandomResizedCrop, :83-84); flip = RandomHorizontalFlip.  Results are
+ * bit-identical to Pillow's.  dst_u8 (N,S,S,3) and / or dst_nchw (N,3,S,S fp32, ToTensor + Normalize(0.5, 0.5)) may be NULL.
+ * ksize >= 2 * ceil(max(1, crop / S)) + 1 over the batch; `workspace` holds wu_image_workspace_bytes(N, S, ksize) bytes. */
+size_t wu_image_geo_bytes(void);
+size_t wu_image_workspace_bytes(int N, int S, int ksize);
+int wu_image_geometry(const uint8_t* src, const void* geo, void* workspace, size_t workspace_bytes,
+                      uint8_t* dst_u8, float* dst_nchw, int N, int S, int ksize, int rot_first, void* stream);
+/* transforms.ColorJitter(brightness, contrast, saturation, hue=0) in place on the (N,S,S,3) uint8 batch: for image n the ops
+ * order[n][0..2] (0 brightness, 1 contrast, 2 saturation, -1 none) with factors[n][op], each Image.blend(degenerate, image, f)
+ * with Pillow's arithmetic; then (dst_nchw != NULL) ToTensor + Normalize(0.5, 0.5) into (N,3,S,S) fp32. */
+int wu_image_color_jitter(uint8_t* img_u8, const float* factors, const int* order, float* dst_nchw, int N, int S, void* stream);
+
 /* layout helpers for the module boundary: NHWC `dtype` <-> NCHW fp32 (feature maps returned by
  * SNDisc.forward, disc.py:38; gradients flowing back into them). */
 int wu_nhwc_to_nchw_f32(const void* x, int ldx, float* y_nchw, int N, int H, int W, int C, int dtype, void* stream);

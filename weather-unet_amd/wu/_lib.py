@@ -63,6 +63,10 @@ SIGNATURES = {
     "wu_stem7x7_dgrad": (I, [P, I, P, P, I, I, I, I, I, P]),
     "wu_maxpool3s2_fwd": (I, [P, I, P, I, P, I, I, I, I, I, P]),
     "wu_maxpool3s2_bwd": (I, [P, I, P, P, I, P, I, I, I, I, I, I, I, P]),
+    "wu_image_geo_bytes": (SZ, []),
+    "wu_image_workspace_bytes": (SZ, [I, I, I]),
+    "wu_image_geometry": (I, [P, P, P, SZ, P, P, I, I, I, I, P]),
+    "wu_image_color_jitter": (I, [P, P, P, P, I, I, P]),
     "wu_prof_begin": (I, [ctypes.c_uint, I]),
     "wu_prof_query": (I, [I, POINTER(c_int), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "wu_prof_end": (I, []),
