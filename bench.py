@@ -30,6 +30,7 @@ GFLOP_FWD_BWD_256 = 254.4      # conv MAC*2, fwd + dgrad + wgrad, per 256x256 im
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+PMC_FILE = "r02_pmc.json"      # scratch/pmc_collect.py output for the current kernels (see roofline.traffic)
 
 
 def parse():
@@ -45,6 +46,9 @@ def parse():
     ap.add_argument("--fwd-only", action="store_true", help="inference forward (eval mode) instead of the training step")
     ap.add_argument("--graph", action="store_true", help="with --fwd-only: replay a hipGraph-captured forward (configs[4])")
     ap.add_argument("--force-ddp", action="store_true", help="initialise RCCL and use the bucketed reducer even with one rank (test hook)")
+    ap.add_argument("--estimator", default="resnet101", choices=["resnet101", "standin"],
+                    help="gan workloads: the frozen estimator in the loop -- the ResNet-101 the reference uses (classifier.py:106, "
+                         "estimator.py:143; random-init weights) or the small stand-in that keeps it out of the step time")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="kernel-variant switch for A/B runs (wu_set_option; defaults are the production choices)")
     ap.add_argument("--launch-check", action="store_true",
@@ -140,7 +144,12 @@ def main():
     gan = None
     if a.workload != "unet":
         from wu.train_step import WeatherTransferStep
-        gan = WeatherTransferStep(5, mode=a.workload[4:], precision=a.precision, device=dev, ddp=use_ddp, seed=0)
+        est = None
+        if a.estimator == "resnet101":
+            from wu.resnet import ResNet101Estimator
+            torch.manual_seed(1)
+            est = ResNet101Estimator(5, precision=a.precision)
+        gan = WeatherTransferStep(5, mode=a.workload[4:], precision=a.precision, device=dev, ddp=use_ddp, seed=0, estimator=est)
         x_rand = (torch.rand((a.batch, 3, a.size, a.size), generator=g) * 2 - 1).to(dev)
         reducer = opt = None
     elif a.fwd_only:
@@ -190,9 +199,11 @@ def main():
     for _ in range(a.warmup):
         step()
     families = [_lib.FAM_CONV_FWD, _lib.FAM_WGRAD, _lib.FAM_CONV_DGRAD]
+    if gan is not None:       # discriminator stride-2 convs and the estimator's pointwise convs
+        families += [_lib.FAM_CONV_S2, _lib.FAM_WGRAD_S2, _lib.FAM_CONV1X1]
     do_roof = (not a.no_roofline) and rank == 0
     if do_roof:
-        _lib.prof_begin(families, 64 * a.steps + 64)
+        _lib.prof_begin(families, (64 if gan is None else 1024) * a.steps + 64)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -205,8 +216,10 @@ def main():
         dt = float(t.item())
 
     roof = None
+    measured_flops = None
     if do_roof:
         stats = {f: _lib.prof_query(f) for f in families}
+        measured_flops = sum(st["flops"] for st in stats.values())     # algorithmic conv FLOPs of the launches in the timed region
         _lib.prof_end()
         # In the training step the weight-gradient kernels run on a second HIP stream beside the data-gradient chain (faster
         # step), so the per-launch durations above include the time a kernel shares the chip.  A short extra pass with that
@@ -227,21 +240,27 @@ def main():
         dom = max(stats, key=lambda f: stats[f]["ms"])
         s = stats[dom]
         peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
-        # HBM bytes per launch from the PMC counters: collected offline with rocprofv3 (separate --pmc passes, gfx950
-        # correction) and committed under profiles/ -- bench.py cannot run the profiler on itself
-        traffic = None
+        # HBM-side bytes per launch from the PMC counters: collected with rocprofv3 in separate --pmc passes (scratch/pmc_collect.py,
+        # gfx950 correction applied) and committed under profiles/ -- bench.py cannot run the profiler on itself.  The file records
+        # the content hash of the kernel sources it was measured on; a library built from other sources gets traffic = null.
+        traffic, traffic_note = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            from wu import _build
+            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as fh:
                 pmc = json.load(fh)
-            key = {_lib.FAM_CONV_FWD: "conv3x3_mfma_v2", _lib.FAM_WGRAD: "conv3x3_wgrad_v2"}.get(dom)
-            if key in pmc and a.precision == "bf16" and a.batch == 32 and a.size == 256 and a.workload == "unet" and not a.fwd_only:
-                traffic = pmc[key]["hbm_bytes_per_launch"]
+            key = {_lib.FAM_CONV_FWD: "conv3x3_mfma_v2_kernel", _lib.FAM_WGRAD: "conv3x3_wgrad_v2_kernel"}.get(dom)
+            same_workload = a.precision == "bf16" and a.batch == 32 and a.size == 256 and a.workload == "unet" and not a.fwd_only
+            if pmc.get("source_hash") != _build.source_hash():
+                traffic_note = f"profiles/{PMC_FILE} was measured on other kernel sources ({str(pmc.get('source_hash'))[:12]} vs {_build.source_hash()[:12]}): not reported"
+            elif key in pmc.get("kernels", {}) and same_workload:
+                traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+                traffic_note = f"profiles/{PMC_FILE}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, same kernel sources ({_build.source_hash()[:12]})"
         except (OSError, ValueError, KeyError):
             traffic = None
         if s["launches"]:
             ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "kernel": _lib.FAMILY_KERNEL[dom], "launches": s["launches"],
+                    "traffic": traffic, "traffic_source": traffic_note, "kernel": _lib.FAMILY_KERNEL[dom], "launches": s["launches"],
                     "algorithmic_bytes_per_launch": round(s["bytes"] / s["launches"]),
                     "avg_launch_ms": round(s["ms"] / s["launches"], 4),
                     "algorithmic_gflop_per_launch": round(s["flops"] / s["launches"] / 1e9, 3),
@@ -264,16 +283,20 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": (f"{'t_' + a.workload[4:] + '_train GAN loop (cUNet + SNDisc + stand-in estimator)' if gan is not None else 'cUNet'} "
+            "config": {"workload": (f"{'t_' + a.workload[4:] + '_train GAN loop (cUNet + SNDisc + estimator)' if gan is not None else 'cUNet'} "
                                     f"{a.size}x{a.size} {a.precision} B={a.batch}/GPU, "
-                                    + ("D update (2 D fwd+bwd, 1 G fwd) + G update (G fwd+bwd, D fwd + data-grad, estimator fwd+data-grad), 2x fused Adam"
+                                    + (f"estimator = {'frozen ResNet-101 (random-init)' if a.estimator == 'resnet101' else 'small stand-in'}; "
+                                       "D update (2 D fwd+bwd, 1 G fwd, 2 estimator fwd) + G update (G fwd+bwd, D fwd + data-grad, 2 estimator fwd + 1 data-grad), 2x fused Adam"
                                        if gan is not None else
                                        ("forward only (eval)" + (", hipGraph replay" if a.graph else "")) if a.fwd_only else
                                        "training step: fwd + bwd (dgrad+wgrad) + grad all-reduce + fused Adam; dropout p=0.3 on; "
                                        "random-init weights, 5-class one-hot, loss mean|G(x,c)-x|")),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                       "algorithmic_tflops": round(value * (GFLOP_FWD_BWD_256 if not a.fwd_only else GFLOP_FWD_BWD_256 / 3)
-                                                   * (a.size / 256) ** 2 / 1e3, 1)},
+                       # conv MAC*2 actually launched in the timed region (3x3 / stride-2 / pointwise families, summed by the launchers) when
+                       # the roofline leg ran on this rank alone; else the analytic per-image figure of the cUNet
+                       "algorithmic_tflops": (round(measured_flops * world / dt / 1e12, 1) if measured_flops and gan is not None else
+                                              round(value * (GFLOP_FWD_BWD_256 if not a.fwd_only else GFLOP_FWD_BWD_256 / 3)
+                                                    * (a.size / 256) ** 2 / 1e3, 1))},
         }
         if roof is not None:
             res["roofline"] = roof

@@ -288,6 +288,133 @@ __global__ __launch_bounds__(256) void adain_upcat_fwd_kernel(const T* __restric
     }
 }
 
+// forward, second formulation ("marching"): a thread owns TWO adjacent output columns of one 16-byte channel chunk and walks down the
+// output rows of its strip.  The two columns interpolate from at most three source columns; per SOURCE row those three chunks are
+// loaded once, mapped through the AdaIN affine (it commutes with the interpolation: the weights sum to one) and reduced
+// horizontally; every output row is then a two-term vertical blend of the current and the next reduced source row.  Per output
+// chunk: 0.75 loads instead of 4, one unpack per source value instead of one per tap.  Same values as adain_upcat_fwd_kernel up to
+// fp32 rounding order (the affine is applied before instead of after the interpolation).
+template <typename T>
+__global__ __launch_bounds__(256) void adain_upcat_fwd_march_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ stats,
+                                       const float* __restrict__ y_std, const float* __restrict__ y_mean,
+                                       T* __restrict__ y, int ldy, int N, int H, int W, int C, int rows_per_strip, int col_tiles,
+                                       float sy, float sx, uint32_t thr, float keep_scale, uint64_t seed,
+                                       const uint64_t* __restrict__ seed_dev, uint8_t* __restrict__ mbits, int mask_in) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    constexpr int LP = 64 / E, PP = 256 / LP;
+    const int tid = threadIdx.x;
+    const int cg = blockIdx.x, n = blockIdx.z;
+    const int ctile = blockIdx.y % col_tiles, strip = blockIdx.y / col_tiles;
+    const int cl = tid % LP, pl = tid / LP;
+    const int c0 = cg * 64 + cl * E;
+    const int cpp = C / E, chunk = c0 / E;
+    const int H2 = 2 * H, W2 = 2 * W;
+    const int j0 = 2 * (ctile * PP + pl), j1 = j0 + 1;                 // this thread's two output columns
+    if (j0 >= W2) return;
+    const bool v1 = j1 < W2;
+    if (seed_dev) seed += *seed_dev;
+    const int r0 = strip * rows_per_strip, r1 = min(H2, r0 + rows_per_strip);
+    if (r0 >= r1) return;
+    // AdaIN affine of this chunk (utils.py:49-50 folded), with the dropout keep-scale folded in
+    float ka[E], kb[E];
+    {
+        float st[2 * E], ys[E], ym[E];
+        const int sc = n * C + c0;
+        ldf<2 * E>(stats + 2 * sc, st);
+        ldf<E>(y_std + sc, ys);
+        ldf<E>(y_mean + sc, ym);
+        const float ds = thr < 0x10000u ? keep_scale : 1.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float a = st[2 * e + 1] * ys[e];
+            ka[e] = a * ds;
+            kb[e] = (ym[e] - st[2 * e] * a) * ds;
+        }
+    }
+    // source columns: c, c+1, c+2 (clamped); column j0 blends (c, c+1) or ... expressed as three weights per output column
+    const Lerp lx0 = src_index(j0, sx, W), lx1 = src_index(min(j1, W2 - 1), sx, W);
+    const int cb = lx0.i0;
+    int cx[3];
+    float w0[3], w1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        cx[k] = min(cb + k, W - 1);
+        w0[k] = (lx0.i0 == cb + k ? lx0.l0 : 0.f) + (lx0.i1 == cb + k && lx0.i1 != lx0.i0 ? lx0.l1 : 0.f) + (lx0.i1 == lx0.i0 && lx0.i0 == cb + k ? lx0.l1 : 0.f);
+        w1[k] = (lx1.i0 == cb + k ? lx1.l0 : 0.f) + (lx1.i1 == cb + k && lx1.i1 != lx1.i0 ? lx1.l1 : 0.f) + (lx1.i1 == lx1.i0 && lx1.i0 == cb + k ? lx1.l1 : 0.f);
+    }
+    const T* base = x + (size_t)n * H * W * ldx + c0;
+    // reduced source rows: A = row `cur`, Bn = row `cur + 1` (two output columns each)
+    float A0[E], A1[E], B0[E], B1[E];
+    auto reduce_row = [&](const uint4 (&q)[3], float* o0, float* o1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) o0[e] = o1[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float v[E];
+            unpack16<T>(q[k], v);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float t = fmaf(v[e], ka[e], kb[e]);
+                o0[e] = fmaf(w0[k], t, o0[e]);
+                o1[e] = fmaf(w1[k], t, o1[e]);
+            }
+        }
+    };
+    auto load_row = [&](int row, uint4 (&q)[3]) __attribute__((always_inline)) {
+        const int rr = min(row, H - 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) q[k] = *(const uint4*)(base + (size_t)(rr * W + cx[k]) * ldx);
+    };
+    int cur = src_index(r0, sy, H).i0;
+    uint4 q[3], qn[3];
+    load_row(cur, q);
+    reduce_row(q, A0, A1);
+    load_row(cur + 1, q);
+    reduce_row(q, B0, B1);
+    load_row(cur + 2, qn);                                             // one source row ahead
+    for (int r = r0; r < r1; ++r) {
+        const Lerp ly = src_index(r, sy, H);
+        if (ly.i0 > cur) {                                             // advances by at most one source row per output row
+#pragma unroll
+            for (int e = 0; e < E; ++e) { A0[e] = B0[e]; A1[e] = B1[e]; }
+            reduce_row(qn, B0, B1);
+            ++cur;
+            load_row(cur + 2, qn);
+        }
+        const float l1w = ly.i1 != ly.i0 ? ly.l1 : 0.f, l0w = ly.i1 != ly.i0 ? ly.l0 : ly.l0 + ly.l1;
+        const size_t rowpix = ((size_t)n * H2 + r) * W2;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            if (side && !v1) continue;
+            const float* a_ = side ? A1 : A0;
+            const float* b_ = side ? B1 : B0;
+            const size_t opix = rowpix + (side ? j1 : j0);
+            float o[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) o[e] = fmaf(l1w, b_[e], l0w * a_[e]);
+            if (thr < 0x10000u) {
+                bool keep[E];
+                if (mask_in) {
+                    const uint32_t bits = mbits[opix * cpp + chunk];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) keep[e] = (bits >> e) & 1u;
+                } else {
+                    keep_bits<E>(seed, (uint64_t)opix * C + c0, thr, keep);
+                    if (mbits) {
+                        uint32_t bits = 0;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) bits |= (keep[e] ? 1u : 0u) << e;
+                        mbits[opix * cpp + chunk] = (uint8_t)bits;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) o[e] = keep[e] ? o[e] : 0.f;
+            }
+            *(uint4*)(y + opix * ldy + c0) = pack16<T>(o);
+        }
+    }
+}
+
 // backward stage A: g'[n,y,x,c] = sum over the output pixels that interpolate from (y,x) of
 // weight * dropout * dy  (the gradient wrt the AdaIN output), plus per-(n,c) sums of g' and g'*xhat.
 template <typename T>
@@ -799,6 +926,21 @@ extern "C" int wu_adain_upcat_fwd(const void* x, int ldx, const float* stats, co
     WU_REQUIRE(!mask_is_input || mask_bits, "adain_upcat_fwd: mask_is_input without mask_bits");
     const float sy = (float)(H - 1) / (float)(2 * H - 1), sx = (float)(W - 1) / (float)(2 * W - 1);
     WU_REQUIRE(((uintptr_t)stats % 16) == 0 && ((uintptr_t)y_std % 16) == 0 && ((uintptr_t)y_mean % 16) == 0, "adain_upcat_fwd: stats alignment");
+    const int LPv = 64 / (16 / esz), PPv = 256 / LPv;          // marching formulation: 2 * PPv output columns per workgroup
+    if (g_wu_opt[WU_OPT_ADAIN_FWD_MARCH] && C % 64 == 0) {
+        const int col_tiles = cdiv(2 * W, 2 * PPv);
+        int strips = cdiv(4096, N * (C / 64) * col_tiles);      // enough workgroups to fill the chip ...
+        if (strips > cdiv(2 * H, 8)) strips = cdiv(2 * H, 8);   // ... but at least 8 output rows per strip (each strip reloads 2-3 source rows)
+        if (strips < 1) strips = 1;
+        const int rows_per_strip = cdiv(2 * H, strips);
+        strips = cdiv(2 * H, rows_per_strip);
+        WU_REQUIRE((long long)col_tiles * strips < 65536, "adain_upcat_fwd: grid too large");
+        DISPATCH_T(dtype, hipLaunchKernelGGL(adain_upcat_fwd_march_kernel<T>, dim3(C / 64, col_tiles * strips, N), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)x, ldx, stats, y_std, y_mean, (T*)y, ldy, N, H, W, C, rows_per_strip, col_tiles, sy, sx,
+                                             keep_thr(p_drop), 1.f / (1.f - p_drop), seed, seed_dev, mask_bits, mask_is_input));
+        WU_LAUNCH_CHECK("adain_upcat_fwd (march)");
+        return 0;
+    }
     const int rows = N * cdiv(2 * H, 4);            // 4 output rows per thread
     const dim3 grid(cdiv(2 * W * (C / (16 / esz)), 256), rows < 32768 ? rows : 32768);
     DISPATCH_T(dtype, hipLaunchKernelGGL(adain_upcat_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
