@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="inference forward (eval mode) instead of the training step")
     ap.add_argument("--graph", action="store_true", help="with --fwd-only: replay a hipGraph-captured forward (configs[4])")
+    ap.add_argument("--dropout-active", action="store_true",
+                    help="with --fwd-only: keep the generator in train mode (Dropout(0.3) active), as the reference's inference scripts do "
+                         "(inference/inf_transfer_c.py:88-96 never calls .eval()); with --graph every replay draws a new mask")
     ap.add_argument("--force-ddp", action="store_true", help="initialise RCCL and use the bucketed reducer even with one rank (test hook)")
     ap.add_argument("--estimator", default="resnet101", choices=["resnet101", "standin"],
                     help="gan workloads: the frozen estimator in the loop -- the ResNet-101 the reference uses (classifier.py:106, "
@@ -153,7 +156,7 @@ def main():
         x_rand = (torch.rand((a.batch, 3, a.size, a.size), generator=g) * 2 - 1).to(dev)
         reducer = opt = None
     elif a.fwd_only:
-        net.eval()
+        net.train(a.dropout_active)
         reducer = opt = None
         if a.graph:
             from wu.graph_infer import GraphedUNet
@@ -288,7 +291,7 @@ def main():
                                     + (f"estimator = {'frozen ResNet-101 (random-init)' if a.estimator == 'resnet101' else 'small stand-in'}; "
                                        "D update (2 D fwd+bwd, 1 G fwd, 2 estimator fwd) + G update (G fwd+bwd, D fwd + data-grad, 2 estimator fwd + 1 data-grad), 2x fused Adam"
                                        if gan is not None else
-                                       ("forward only (eval)" + (", hipGraph replay" if a.graph else "")) if a.fwd_only else
+                                       (("forward only, Dropout(0.3) active" if a.dropout_active else "forward only (eval)") + (", hipGraph replay" if a.graph else "")) if a.fwd_only else
                                        "training step: fwd + bwd (dgrad+wgrad) + grad all-reduce + fused Adam; dropout p=0.3 on; "
                                        "random-init weights, 5-class one-hot, loss mean|G(x,c)-x|")),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",

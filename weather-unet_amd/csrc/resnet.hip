@@ -48,17 +48,28 @@ template <> struct PwMma<float> {      // exact fp32: four 32x32x2 steps per 16-
     }
 };
 
+// four consecutive channels with ONE load (8 bytes of bf16 / 16 bytes of fp32)
+template <typename T> __device__ __forceinline__ void load4(const T* p, float* o);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float* o) {
+    const float4 v = *(const float4*)p;
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float* o) {
+    const uint2 v = *(const uint2*)p;
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
 // LDS image: 128-byte rows, the eight 16-byte slots of a row XOR-swizzled with (row & 7): a ds_read_b128 of 8 consecutive rows at
 // one logical slot touches all 32 banks once
 __device__ __forceinline__ int pw_off(int row, int slot) { return row * kKB + ((slot ^ (row & 7)) << 4); }
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[(kTM + kTN) * kKB];      // 40 KiB: two workgroups per CU cover each other's barriers
+    extern __shared__ __attribute__((aligned(16))) char smem[];                // two stages of 40 KiB: two workgroups per CU
     constexpr int E16 = 16 / (int)sizeof(T);                                    // elements per 16-byte slot
     constexpr int KE = kKB / (int)sizeof(T);                                    // channels per K step
-    char* a_lds = smem;
-    char* w_lds = smem + kTM * kKB;
+    constexpr int kStage = (kTM + kTN) * kKB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
 
@@ -92,19 +103,24 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) wsrc[k] = (const T*)a.w + (size_t)(co0 + srow + 32 * k) * a.Cin + sslot * E16;
 
-    uint4 areg[8], wreg[2];
+    uint4 areg[8], wr0, wr1;            // the weight pair is named, not an array: hipcc parks a small array of uint4 in scratch here
     auto load_step = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) areg[k] = *(const uint4*)(asrc[k] + c0);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) wreg[k] = *(const uint4*)(wsrc[k] + c0);
+        wr0 = *(const uint4*)(wsrc[0] + c0);
+        wr1 = *(const uint4*)(wsrc[1] + c0);
     };
-    auto store_step = [&]() __attribute__((always_inline)) {
-        const uint4 z = make_uint4(0, 0, 0, 0);
+    auto store_step = [&](int stage) __attribute__((always_inline)) {
+        char* a_lds = smem + stage * kStage;
+        char* w_lds = a_lds + kTM * kKB;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) *(uint4*)(a_lds + pw_off(srow + 32 * k, sslot)) = aok[k] ? areg[k] : z;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) *(uint4*)(w_lds + pw_off(srow + 32 * k, sslot)) = wreg[k];
+        for (int k = 0; k < 8; ++k) {
+            // rows past the end of the GEMM are zeroed with a lane mask (a 128-bit select is lowered through scratch memory)
+            const uint32_t m = aok[k] ? 0xffffffffu : 0u;
+            *(uint4*)(a_lds + pw_off(srow + 32 * k, sslot)) = make_uint4(areg[k].x & m, areg[k].y & m, areg[k].z & m, areg[k].w & m);
+        }
+        *(uint4*)(w_lds + pw_off(srow, sslot)) = wr0;
+        *(uint4*)(w_lds + pw_off(srow + 32, sslot)) = wr1;
     };
 
     // accumulators TRANSPOSED (weights are the MFMA A operand): a lane owns 4 consecutive channels of one pixel per register quad
@@ -116,12 +132,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
+    // K loop, two LDS stages: the global loads of step c+1 are in flight under the MFMAs of step c and land in the OTHER stage,
+    // so one barrier per step suffices (everyone has left stage (c+1)&1 when it passed the barrier that published stage c&1)
     const int nsteps = a.Cin / KE;
     load_step(0);
-    store_step();
+    store_step(0);
     __syncthreads();
     for (int c = 0; c < nsteps; ++c) {
         if (c + 1 < nsteps) load_step((c + 1) * KE);
+        const char* a_lds = smem + (c & 1) * kStage;
+        const char* w_lds = a_lds + kTM * kKB;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             uint4 af[2], bf[2];
@@ -134,9 +154,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) PwMma<T>::run(acc[mi][ni], bf[ni], af[mi]);      // D^T = W * X^T
         }
-        __syncthreads();
         if (c + 1 < nsteps) {
-            store_step();
+            store_step((c + 1) & 1);
             __syncthreads();
         }
     }
@@ -175,16 +194,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = own ? v[e] : 0.f;
                         if (a.res) {
-                            const T* rp = (const T*)a.res + p * a.ldres + co;
+                            float rv[4];
+                            load4<T>((const T*)a.res + p * a.ldres + co, rv);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] += ElemTraits<T>::load(rp + e);
+                            for (int e = 0; e < 4; ++e) o[e] += rv[e];
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = act_apply(o[e], a.act);
                         if (a.egate) {
-                            const T* ep = (const T*)a.egate + p * a.ldegate + co;
+                            float ev[4];
+                            load4<T>((const T*)a.egate + p * a.ldegate + co, ev);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = act_gate(o[e], ElemTraits<T>::load(ep + e), a.egate_act);
+                            for (int e = 0; e < 4; ++e) o[e] = act_gate(o[e], ev[e], a.egate_act);
                         }
                         T* yp = (T*)a.y + p * a.ldy + co;
                         if constexpr (std::is_same<T, float>::value) {
@@ -446,7 +467,14 @@ extern "C" int wu_conv1x1_fwd(const void* x, int ldx, const void* w, const float
     WU_REQUIRE(grid < (1ll << 31), "conv1x1_fwd: grid too large");
     hipStream_t s = (hipStream_t)stream;
     wu_prof_pre(WU_FAM_CONV1X1, s);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(conv1x1_mfma_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s, a));
+    constexpr int kLds = 2 * (kTM + kTN) * kKB;              // 80 KiB
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        attr_set = true;
+    }
+    DISPATCH_T(dtype, hipLaunchKernelGGL(conv1x1_mfma_kernel<T>, dim3((unsigned)grid), dim3(256), kLds, s, a));
     wu_prof_post(WU_FAM_CONV1X1, s, 2.0 * (double)a.M * Cin * Cout, ((double)a.M * (Cin + Cout * (residual ? 2 : 1)) + (double)Cin * Cout) * esz);
     WU_LAUNCH_CHECK("conv1x1_mfma");
     return 0;
