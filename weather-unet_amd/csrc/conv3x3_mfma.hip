@@ -188,7 +188,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int item = item0 + 256 * u;
-                if (item < nitems) *(uint4*)(halo_lds + swz_off(item >> 2, item & 3)) = okv[u] ? v[u] : zero4;
+                if (item < nitems) {
+                    // zero padding as a lane mask: a 128-bit select between a register and a constant is lowered through scratch memory
+                    const uint32_t m = okv[u] ? 0xffffffffu : 0u;
+                    *(uint4*)(halo_lds + swz_off(item >> 2, item & 3)) = make_uint4(v[u].x & m, v[u].y & m, v[u].z & m, v[u].w & m);
+                }
             }
         }
 #define WU_COPYW(t) *(uint4*)(w_lds + (t) * (kBN * kChunkBytes) + wdst) = *(const uint4*)(wsrc + (t) * wtap_stride + c0);

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradArgs a
                     if (item < nitems) {
                         const int p = item / SLOTS, s = item % SLOTS;
                         const int hy = p / a.halo_w, hx = p - hy * a.halo_w;
-                        *(uint4*)(x_lds + lds_off<T>(p, hx, s * 16)) = okv[u] ? v[u] : make_uint4(0, 0, 0, 0);
+                        const uint32_t m = okv[u] ? 0xffffffffu : 0u;      // lane mask, not a 128-bit select (lowered through scratch)
+                        *(uint4*)(x_lds + lds_off<T>(p, hx, s * 16)) = make_uint4(v[u].x & m, v[u].y & m, v[u].z & m, v[u].w & m);
                     }
                 }
             }
