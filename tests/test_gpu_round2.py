@@ -356,3 +356,23 @@ def test_batched_evaluation_matches_oracle_loop(mode):
     got_idx, _ = st.evaluation(images.to(DEV), idx.to(DEV), ref_labels.to(DEV))
     got_oh, _ = st.evaluation(images.to(DEV), torch.eye(nc)[idx].to(DEV), ref_labels.to(DEV))
     assert torch.equal(got_idx["d_loss"], got_oh["d_loss"])
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_sndisc_gradients_are_bitwise_reproducible(precision):
+    """Round 1 left fp32 atomics in the weight gradients of SNDisc's image-layout convs (3->3 and 3->64 stride 2, every variant
+    except the bf16 64-channel one); they now write per-workgroup partials into the caller's slab and are folded in workgroup
+    order, like the other thin layers: every D gradient of the hinge loss, and the image gradient, repeat bit for bit."""
+    nc, seed = 5, 5
+    x, c = (t.to(DEV) for t in O.make_inputs(4, 96, nc, seed, True))
+    runs = []
+    for _ in range(3):
+        d = _make_d(nc, seed, precision).train()
+        xr = x.clone().requires_grad_(True)
+        out = d(xr, c)[0]
+        torch.mean(torch.relu(1.0 - out)).backward()
+        runs.append(({k: p.grad.clone() for k, p in d.named_parameters()}, xr.grad.clone()))
+    for g, gx in runs[1:]:
+        assert torch.equal(gx, runs[0][1])
+        for k in g:
+            assert torch.equal(g[k], runs[0][0][k]), f"{k} differs between runs"

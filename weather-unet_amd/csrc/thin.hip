@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_rows_kernel(const float* _
 template <typename T, int STRIDE, bool DY_NCHW>
 __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_kernel(const float* __restrict__ x, const void* __restrict__ dyv, int lddy,
                                                                const void* __restrict__ yv, int ldy, int act,
-                                                               float* __restrict__ dw, float* __restrict__ dbias,
+                                                               float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ part,
                                                                int N, int H, int W, int Cout) {
     __shared__ float patch[27][64];
     __shared__ float dyl[64][65];
@@ -284,12 +284,15 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_kernel(const float* __re
         __syncthreads();
     }
     if (cog + co < Cout) {
+        // part != NULL (Cout <= 64, one cout group): this workgroup's slice of the partial-sum slab, folded in workgroup order by
+        // thin_fold_kernel (dW at [co*27 + k], dbias behind it at [Cout*27 + co]); else fp32 atomics
+        float* mine = part ? part + (size_t)blockIdx.x * (64 * 27 + 64) : nullptr;
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int k = q + 4 * j;
-            if (k < 27) atomicAdd(&dw[(size_t)(cog + co) * 27 + k], acc[j]);
+            if (k < 27) { if (mine) mine[co * 27 + k] = acc[j]; else atomicAdd(&dw[(size_t)(cog + co) * 27 + k], acc[j]); }
         }
-        if (q == 0 && dbias) atomicAdd(&dbias[cog + co], bsum);
+        if (q == 0 && dbias) { if (mine) mine[Cout * 27 + co] = bsum; else atomicAdd(&dbias[cog + co], bsum); }
     }
 }
 
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_dgrad_nhwc_kernel(const T* __r
 template <int STRIDE>
 __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_small_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                      const float* __restrict__ y, int act, float* __restrict__ dw,
-                                                                     float* __restrict__ dbias, int N, int H, int W, int Cout) {
+                                                                     float* __restrict__ dbias, float* __restrict__ part, int N, int H, int W, int Cout) {
     __shared__ float red[4][84];
     const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
     const long long total = (long long)N * Ho * Wo;
@@ -639,10 +642,11 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_small_kernel(const float
     __syncthreads();
     if (threadIdx.x < 84) {
         const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        float* mine = part ? part + (size_t)blockIdx.x * (64 * 27 + 64) : nullptr;      // slab slice: dW [Cout*27], then dbias [Cout]
         if (threadIdx.x < 81) {
-            if (threadIdx.x / 27 < Cout) atomicAdd(&dw[threadIdx.x], v);
+            if (threadIdx.x / 27 < Cout) { if (mine) mine[threadIdx.x] = v; else atomicAdd(&dw[threadIdx.x], v); }
         } else if (dbias && threadIdx.x - 81 < Cout) {
-            atomicAdd(&dbias[threadIdx.x - 81], v);
+            if (mine) mine[Cout * 27 + threadIdx.x - 81] = v; else atomicAdd(&dbias[threadIdx.x - 81], v);
         }
     }
 }
@@ -805,14 +809,15 @@ extern "C" int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const bool mfma_path = !dy_nchw && dtype == WU_BF16 && Cout == 64 && ((uintptr_t)dy % 16) == 0 && (lddy % 8) == 0 &&
                            (!y || (((uintptr_t)y % 16) == 0 && (ldy_ % 8) == 0));
-    // deterministic mode: the production (bf16, 64-channel) path with a caller-owned slab for the per-workgroup partials
-    float* part = (mfma_path && workspace && workspace_bytes >= wu_thin_workspace_bytes() && ((uintptr_t)workspace % 16) == 0) ? (float*)workspace : nullptr;
+    // deterministic mode (every variant with Cout <= 64): a caller-owned slab receives the per-workgroup partials, thin_fold_kernel sums
+    // them in workgroup order; without the slab the kernels fall back to fp32 atomics
+    float* part = (Cout <= 64 && workspace && workspace_bytes >= wu_thin_workspace_bytes() && ((uintptr_t)workspace % 16) == 0) ? (float*)workspace : nullptr;
     if (!accumulate && !part) {
         hipMemsetAsync(dw_oihw, 0, (size_t)Cout * 27 * sizeof(float), s);
         if (dbias) hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
     }
     dim3 grid(grid_cap((long long)N * Ho * Wo, 64, 1024), cdiv(Cout, 64));
-#define C3W(T, ST, NCHW) hipLaunchKernelGGL((conv3x3_c3_wgrad_kernel<T, ST, NCHW>), grid, dim3(256), 0, s, x_nchw, dy, lddy, y, ldy_, act, dw_oihw, dbias, N, H, W, Cout)
+#define C3W(T, ST, NCHW) hipLaunchKernelGGL((conv3x3_c3_wgrad_kernel<T, ST, NCHW>), grid, dim3(256), 0, s, x_nchw, dy, lddy, y, ldy_, act, dw_oihw, dbias, part, N, H, W, Cout)
     if (mfma_path) {
         const long long ntiles = ((long long)N * Ho * Wo + 255) / 256;
         const int g = (int)(ntiles < kThinMaxBlocks ? ntiles : kThinMaxBlocks);
@@ -824,8 +829,9 @@ extern "C" int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy
     }
     if (dy_nchw && Cout <= 3) {
         const int g = grid_cap((long long)N * Ho * Wo, 256, 1024);
-        if (stride == 1) hipLaunchKernelGGL(conv3x3_c3_wgrad_small_kernel<1>, dim3(g), dim3(256), 0, s, x_nchw, (const float*)dy, (const float*)y, act, dw_oihw, dbias, N, H, W, Cout);
-        else hipLaunchKernelGGL(conv3x3_c3_wgrad_small_kernel<2>, dim3(g), dim3(256), 0, s, x_nchw, (const float*)dy, (const float*)y, act, dw_oihw, dbias, N, H, W, Cout);
+        if (stride == 1) hipLaunchKernelGGL(conv3x3_c3_wgrad_small_kernel<1>, dim3(g), dim3(256), 0, s, x_nchw, (const float*)dy, (const float*)y, act, dw_oihw, dbias, part, N, H, W, Cout);
+        else hipLaunchKernelGGL(conv3x3_c3_wgrad_small_kernel<2>, dim3(g), dim3(256), 0, s, x_nchw, (const float*)dy, (const float*)y, act, dw_oihw, dbias, part, N, H, W, Cout);
+        if (part) hipLaunchKernelGGL(thin_fold_kernel, dim3(cdiv(Cout * 28, 8)), dim3(256), 0, s, part, g, kC3Slab, dw_oihw, Cout * 27, dbias, dbias ? Cout : 0, accumulate);
         WU_LAUNCH_CHECK("conv3x3_c3_wgrad_small");
         return 0;
     }
@@ -833,6 +839,7 @@ extern "C" int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy
     else if (dtype == WU_BF16) { if (stride == 1) C3W(bf16_t, 1, false); else C3W(bf16_t, 2, false); }
     else { if (stride == 1) C3W(float, 1, false); else C3W(float, 2, false); }
 #undef C3W
+    if (part) hipLaunchKernelGGL(thin_fold_kernel, dim3(cdiv(Cout * 28, 8)), dim3(256), 0, s, part, (int)grid.x, kC3Slab, dw_oihw, Cout * 27, dbias, dbias ? Cout : 0, accumulate);
     WU_LAUNCH_CHECK("conv3x3_c3_wgrad");
     return 0;
 }
