@@ -219,70 +219,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradArgs a
 }
 
 // Fixed-order reduction of the split-K partials slab[tap][co][split][ci] (+ bias partials [split][Cout]) into OIHW fp32.
-// One block per (co, tap): its splits x Cin partials are ONE contiguous run, read as float4 by TX = Cin/4 lanes x G split
-// groups (group g takes splits g, g+G, ...; every load of an iteration is independent); the G partial sums are combined
-// in group order through LDS -> deterministic for a given (splits, Cin).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab, float* __restrict__ dw,
-                                                           float* __restrict__ dbias, int splits, int Cout, int Cin, int accumulate) {
-    __shared__ float4 red[256];
-    const int co = blockIdx.x, t = blockIdx.y;
+// One WAVE per (co, tap) row: its splits x Cin partials are ONE contiguous run, read as float4 by TX (a power of two <= Cin/4, 64) lanes x
+// G = 64/TX split groups (group g takes splits g, g+G, ...); the G partial sums are combined with xor-shuffles in a fixed tree ->
+// deterministic for a given (splits, Cin).  No LDS and <= 32 registers, on purpose: the reducer follows every weight-gradient
+// launch on the side stream, and a workgroup that needs LDS or a 64-register wave cannot be placed on a CU whose 160 KiB / 480 of
+// 512 registers per SIMD lane are held by a persistent conv workgroup -- it then waits for a whole conv KERNEL to retire (measured:
+// 90 us per reducer in the step against 12 us stand-alone).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void wgrad_reduce_kernel(
+    const float* __restrict__ slab, const float* __restrict__ bslab, float* __restrict__ dw, float* __restrict__ dbias,
+    int splits, int Cout, int Cin, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);          // (co, tap) rows, tap fastest: row = co * 9 + t
+    if (row >= Cout * 9) return;
+    const int co = row / 9, t = row - co * 9;
     const int c4n = Cin >> 2;
-    const int TX = c4n < 256 ? c4n : 256;
-    const int G = 256 / TX;
-    const int tx = threadIdx.x % TX, g = threadIdx.x / TX;
-    const float* row = slab + ((size_t)t * Cout + co) * splits * Cin;
-    for (int c4 = tx; c4 < c4n; c4 += TX) {          // one pass unless Cin > 1024
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g < G) {
-            float4 a4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float* p = row + c4 * 4;
-            int k = g;
-            for (; k + 3 * G < splits; k += 4 * G) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 v = *(const float4*)(p + (size_t)(k + u * G) * Cin);
-                    a4[u].x += v.x; a4[u].y += v.y; a4[u].z += v.z; a4[u].w += v.w;
-                }
-            }
-            for (; k < splits; k += G) {
-                const float4 v = *(const float4*)(p + (size_t)k * Cin);
-                a4[0].x += v.x; a4[0].y += v.y; a4[0].z += v.z; a4[0].w += v.w;
-            }
-            s.x = (a4[0].x + a4[1].x) + (a4[2].x + a4[3].x); s.y = (a4[0].y + a4[1].y) + (a4[2].y + a4[3].y);
-            s.z = (a4[0].z + a4[1].z) + (a4[2].z + a4[3].z); s.w = (a4[0].w + a4[1].w) + (a4[2].w + a4[3].w);
+    int TX = 64;                                                  // lanes across ci (float4 each): the largest power of two <= min(Cin/4, 64)
+    while (TX > c4n) TX >>= 1;
+    const int G = 64 / TX;
+    const int tx = lane & (TX - 1), g = lane / TX;
+    const float* base = slab + ((size_t)t * Cout + co) * splits * Cin;
+    for (int c4b = 0; c4b < c4n; c4b += TX) {                     // wave-uniform trip count (the shuffles below need every lane)
+        const int c4 = c4b + tx;
+        const bool valid = c4 < c4n;
+        const float* p = base + (valid ? c4 : 0) * 4;
+        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);           // one chain: registers are what places this kernel beside a conv workgroup
+        for (int k = g; k < splits; k += G) {
+            const float4 v0 = *(const float4*)(p + (size_t)k * Cin);
+            sacc.x += v0.x; sacc.y += v0.y; sacc.z += v0.z; sacc.w += v0.w;
         }
-        if (G > 1) {
-            __syncthreads();
-            red[threadIdx.x] = s;
-            __syncthreads();
-            if (g == 0)
-                for (int j = 1; j < G; ++j) { const float4 v = red[j * TX + tx]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        for (int m = TX; m < 64; m <<= 1) {                       // combine the G groups (lanes tx + j * TX): fixed xor tree
+            sacc.x += __shfl_xor(sacc.x, m); sacc.y += __shfl_xor(sacc.y, m);
+            sacc.z += __shfl_xor(sacc.z, m); sacc.w += __shfl_xor(sacc.w, m);
         }
-        if (g == 0) {
+        if (g == 0 && valid) {
             float* o = dw + ((size_t)co * Cin + c4 * 4) * 9 + t;
-            if (accumulate) { o[0] += s.x; o[9] += s.y; o[18] += s.z; o[27] += s.w; }
-            else { o[0] = s.x; o[9] = s.y; o[18] = s.z; o[27] = s.w; }
+            if (accumulate) { o[0] += sacc.x; o[9] += sacc.y; o[18] += sacc.z; o[27] += sacc.w; }
+            else { o[0] = sacc.x; o[9] = sacc.y; o[18] = sacc.z; o[27] = sacc.w; }
         }
     }
-    if (dbias && t == 0) {      // bias partials [split][Cout]: one load per thread, fixed-shape tree through LDS
+    if (dbias && t == 0) {      // bias partials [split][Cout]: lanes stride the splits, xor-shuffle tree
         float b = 0.f;
-        for (int k = threadIdx.x; k < splits; k += 256) b += bslab[(size_t)k * Cout + co];
-        float* rf = (float*)red;
-        __syncthreads();
-        rf[threadIdx.x] = b;
-        __syncthreads();
-        for (int w = 128; w > 0; w >>= 1) {
-            if ((int)threadIdx.x < w) rf[threadIdx.x] += rf[threadIdx.x + w];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) dbias[co] = accumulate ? dbias[co] + rf[0] : rf[0];
+        for (int k = lane; k < splits; k += 64) b += bslab[(size_t)k * Cout + co];
+        for (int m = 1; m < 64; m <<= 1) b += __shfl_xor(b, m);
+        if (lane == 0) dbias[co] = accumulate ? dbias[co] + b : b;
     }
 }
 
 void launch_wgrad_reduce(const float* slab, const float* bslab, float* dw, float* dbias, int splits, int Cout, int Cin, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout, 9), dim3(256), 0, s, slab, bslab, dw, dbias, splits, Cout, Cin, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(Cout * 9, 4)), dim3(256), 0, s, slab, bslab, dw, dbias, splits, Cout, Cin, accumulate);
 }
 
 struct WPlan { int P, twl, tiles_x, tiles_y, ntiles, splits, halo_w, halo_h; size_t lds, ws; };
