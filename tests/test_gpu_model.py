@@ -360,14 +360,14 @@ def test_gan_step_matches_oracle(mode, supervised, cross_ent):
     assert r["worst_d"] >= 0.999 and r["worst_g"] >= 0.995
 
 
-@pytest.mark.parametrize("mode", ["cls", "est"])
-def test_gan_step_bf16(mode):
+@pytest.mark.parametrize("mode,size", [("cls", 64), ("est", 64), ("cls", 256)])
+def test_gan_step_bf16(mode, size):
     """The same two steps in the bf16 production mode (configs[2] / configs[3] arithmetic).  Tolerances: losses within 5e-2
     relative (north_star's bf16 forward tolerance; the hinge / reconstruction terms are means of O(1) values), D gradients
     cosine >= 0.98, G gradients cosine >= 0.9 (they cross D, the estimator and ~30 bf16-rounded gated ops; the per-layer
     figures are printed; the tight bf16 check of G's own backward is test_bf16_gradients_vs_emulating_oracle)."""
-    r = _gan_case(mode, "bf16")
-    print(f"bf16 GAN step {mode}: d_loss err {r['d_loss_err']:.2e}, g_loss err {r['g_loss_err']:.2e}, worst D cos {r['worst_d']:.5f}, "
+    r = _gan_case(mode, "bf16", size=size)            # size 256 = BASELINE configs[2]'s resolution (B=2: the CPU oracle's budget)
+    print(f"bf16 GAN step {mode} {size}x{size}: d_loss err {r['d_loss_err']:.2e}, g_loss err {r['g_loss_err']:.2e}, worst D cos {r['worst_d']:.5f}, "
           f"worst G cos {r['worst_g']:.5f}")
     for k, v in r["per_layer"].items():
         print(f"   {k:24s} cos {v:.5f}")

@@ -231,9 +231,12 @@ class UNetFn(Function):
             wgrad(name, 2, mid, g_out_gated)
             g_mid = K.conv3x3(g_out_gated, wd[name + ".2"], None, _new(*mid.shape, dt, dev), egate=mid, egate_act=RELU)
             if name == "dconv_down1":
+                # the first conv's weight gradient is the LAST kernel of the backward chain and nothing consumes it: it joins the
+                # other weight gradients on the side stream (which has slack) instead of extending the main stream's tail
                 dw, db, acc = grad_bufs(0)
-                K.conv3x3_c3_wgrad(xin, g_mid, dw, db, 1, code, accumulate=acc)
-                done((name, 0), 0, dw, db)
+                router.on_side(lambda: (K.conv3x3_c3_wgrad(xin, g_mid, dw, db, 1, code, accumulate=acc), done((name, 0), 0, dw, db)))
+                if side is not None:
+                    keep.append((xin, g_mid, dw, db))
                 return g_mid
             wgrad(name, 0, xin, g_mid)
             if not need_dx:
