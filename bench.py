@@ -289,7 +289,7 @@ def main():
             "config": {"workload": (f"{'t_' + a.workload[4:] + '_train GAN loop (cUNet + SNDisc + estimator)' if gan is not None else 'cUNet'} "
                                     f"{a.size}x{a.size} {a.precision} B={a.batch}/GPU, "
                                     + (f"estimator = {'frozen ResNet-101 (random-init)' if a.estimator == 'resnet101' else 'small stand-in'}; "
-                                       "D update (2 D fwd+bwd, 1 G fwd, 2 estimator fwd) + G update (G fwd+bwd, D fwd + data-grad, 2 estimator fwd + 1 data-grad), 2x fused Adam"
+                                       "one estimator pass over cat(rand_images, images) (the reference's three no-grad calls), D update (2 D fwd+bwd, 1 G fwd) + G update (G fwd+bwd, D fwd + data-grad, estimator fwd + data-grad), 2x fused Adam"
                                        if gan is not None else
                                        (("forward only, Dropout(0.3) active" if a.dropout_active else "forward only (eval)") + (", hipGraph replay" if a.graph else "")) if a.fwd_only else
                                        "training step: fwd + bwd (dgrad+wgrad) + grad all-reduce + fused Adam; dropout p=0.3 on; "

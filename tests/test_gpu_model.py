@@ -517,3 +517,30 @@ def test_side_stream_wgrad_is_bitwise_neutral():
         UG.SIDE_STREAM_WGRAD = True
     for k in grads[True]:
         assert torch.equal(grads[True][k], grads[False][k]), k
+
+
+@pytest.mark.parametrize("mode", ["cls", "est"])
+def test_step_shares_the_estimator_forwards(mode):
+    """``step()`` runs the frozen estimator once on cat(rand_images, images) instead of the reference's three no-grad calls
+    (t_cls_train.py:424, :297, :237 -- the last two on the same batch): one iteration must give the losses of the call-by-call
+    sequence (fp32; two identically seeded harnesses)."""
+    from wu.train_step import WeatherTransferStep
+    nc, seed = 5, 9
+    x, _ = O.make_inputs(2, 64, nc, seed, True)
+    xr, _ = O.make_inputs(2, 64, nc, seed + 1, True)
+    xd, xrd = x.to(DEV), xr.to(DEV)
+    res = []
+    for shared in (True, False):
+        st = WeatherTransferStep(nc, mode=mode, precision="fp32", device=DEV, ddp=False, seed=3)
+        st.inference.load_state_dict(O.make_cunet_params(nc, seed))
+        st.discriminator.load_state_dict(O.make_sndisc_params(nc, seed))
+        st.inference.dropout_seed = 4
+        if shared:
+            out = st.step(xd, xrd)
+        else:
+            with torch.no_grad():
+                rl = st.estimator(xrd)
+            out = (st.update_discriminator(xd, rl),) + st.update_inference(xd, rl)
+        res.append([t.item() for t in out])
+    for a, b in zip(*res):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), res

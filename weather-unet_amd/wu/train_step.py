@@ -14,6 +14,10 @@ Differences from the reference loop, all numerically neutral:
     t_cls_train.py:302-303);
   * no ``.item()`` host syncs inside the step (the reference forces six per step, :275-282,310-312): losses are
     returned as device tensors;
+  * ``step()`` evaluates the frozen, eval-mode estimator ONCE on ``cat(rand_images, images)``: the reference runs it on
+    ``rand_images`` (:424) and then twice on the same ``images`` (:297 in update_discriminator, :237 in update_inference), three
+    no-grad forwards of a deterministic function of which two are identical; the one call on the concatenated batch returns the
+    same numbers (no cross-sample coupling in eval-mode BatchNorm) with half the launches and twice the GEMM rows;
   * evaluation() runs its B transfers as ONE (B*B)-image pass of G / D / estimator instead of B passes (SURVEY.md 8f.4);
   * data parallel (new): G and D gradients are averaged by two ``GradBucketReducer``s; the D
     gradients that g_loss.backward() deposits (and the next d_opt.zero_grad() discards, t_cls_train.py:291) are
@@ -83,14 +87,18 @@ class WeatherTransferStep:
         return torch.softmax(y, dim=1) if self.mode == "cls" else y
 
     # ------------------------------------------------------------------ t_cls_train.py:288-312 / t_est_train.py:261-283
-    def update_discriminator(self, images, labels, c_d=None):
+    def update_discriminator(self, images, labels, c_d=None, pred_labels=None):
+        """``pred_labels``: ``self.estimator(images)`` if the caller already has it (step() does); computed here otherwise."""
         if self.d_red is not None:
             self.d_red.enabled = True
             self.d_red.zero_grad()
         else:
             self.d_opt.zero_grad(set_to_none=True)
         with torch.no_grad():
-            pred_labels = c_d if self.supervised else self.estimator(images)             # :294-297
+            if self.supervised:
+                pred_labels = c_d                                                        # :294-295
+            elif pred_labels is None:
+                pred_labels = self.estimator(images)                                     # :297
             fake_out = self.inference(images, labels)                                    # :302-303
         real_d_out_pred = self.discriminator(images, pred_labels)[0]                     # :299
         fake_d_out = self.discriminator(fake_out, labels)[0]
@@ -102,14 +110,17 @@ class WeatherTransferStep:
         return d_loss.detach()
 
     # ------------------------------------------------------------------ t_cls_train.py:226-286 / t_est_train.py:214-259
-    def update_inference(self, images, r_labels, d_labels=None, r_labels_=None):
+    def update_inference(self, images, r_labels, d_labels=None, r_labels_=None, pred_labels=None):
         if self.g_red is not None:
             self.g_red.zero_grad()
             self.d_red.enabled = False             # D's gradients from this backward are discarded, not reduced
         else:
             self.g_opt.zero_grad(set_to_none=True)
         with torch.no_grad():
-            pred_labels = d_labels if self.supervised else self.estimator(images)        # :232-237
+            if self.supervised:
+                pred_labels = d_labels                                                   # :232-235
+            elif pred_labels is None:
+                pred_labels = self.estimator(images)                                     # :237
         # D's parameter gradients from this backward would be thrown away by the next d_opt.zero_grad()
         # (t_cls_train.py:291): do not compute them (only the data-gradient path through D is needed)
         d_params = list(self.discriminator.parameters())
@@ -151,14 +162,18 @@ class WeatherTransferStep:
             eye = torch.eye(nc, device=images.device)
             rand_labels, d_labels = eye[c_r], eye[c_d]                                   # :420-421
             r_idx = c_r                                                                  # :432
+            pred_labels = None
         else:
             with torch.no_grad():
-                raw = self.estimator_(rand_images)
+                # estimator(rand_images) (:424) and estimator(images) (:297, :237) in one pass over the concatenated batch
+                raw_all = self.estimator_(torch.cat([rand_images, images]))
+                raw, raw_img = raw_all[:rand_images.shape[0]], raw_all[rand_images.shape[0]:]
                 rand_labels = torch.softmax(raw, dim=1) if self.mode == "cls" else raw   # :423
+                pred_labels = torch.softmax(raw_img, dim=1) if self.mode == "cls" else raw_img
             d_labels = None
             r_idx = (c_r if c_r is not None else torch.argmax(raw, dim=1)) if self.cross_ent else None   # :436,438
-        d_loss = self.update_discriminator(images, rand_labels, d_labels)                # :429
-        g_losses = self.update_inference(images, rand_labels, d_labels, r_idx)           # :432-438
+        d_loss = self.update_discriminator(images, rand_labels, d_labels, pred_labels)   # :429
+        g_losses = self.update_inference(images, rand_labels, d_labels, r_idx, pred_labels)   # :432-438
         return (d_loss,) + g_losses
 
     # ------------------------------------------------------------------ t_cls_train.py:314-367 / t_est_train.py:285-332
