@@ -30,21 +30,23 @@ __global__ __launch_bounds__(256) void adain_style_fwd_kernel(const float* __res
     if (y4) *(float4*)(y4 + (size_t)idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// one thread per weight row r = 4c + k: dW[r][:] = sum_n g[n] y[n][:], db[r] = sum_n g[n],
-// g[n] = d_mean[n,c]/4 + d_std[n,c] * (y4[n,c,k] - mean) / (3 std)
+// EIGHT lanes per weight row r = 4c + k: dW[r][:] = sum_n g[n] y[n][:], db[r] = sum_n g[n],
+// g[n] = d_mean[n,c]/4 + d_std[n,c] * (y4[n,c,k] - mean) / (3 std).  Lane `sub` takes the samples n = sub, sub + 8, ...; the eight
+// partial sums are combined with a fixed xor-shuffle tree (deterministic).  One thread walking all N samples was a chain of N
+// dependent memory round trips: 38 us per launch for half a megabyte, three times at the very end of every backward pass.
 __global__ __launch_bounds__(256) void adain_style_bwd_kernel(const float* __restrict__ d_std, const float* __restrict__ d_mean,
                                                               const float* __restrict__ y, const float* __restrict__ y4,
                                                               const float* __restrict__ y_std, const float* __restrict__ y_mean,
                                                               float* __restrict__ dw, float* __restrict__ db, int N, int C, int nc, int accumulate) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= 4 * C) return;
-    const int c = r >> 2, k = r & 3;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int r = t >> 3, sub = t & 7;
+    const bool valid = r < 4 * C;                   // every lane stays for the shuffles
+    const int c = (valid ? r : 0) >> 2, k = r & 3;
     float acc[kMaxNc];
 #pragma unroll
     for (int j = 0; j < kMaxNc; ++j) acc[j] = 0.f;
     float bs = 0.f;
-#pragma unroll 8
-    for (int n = 0; n < N; ++n) {       // loads of 8 samples in flight (the accumulation order stays n = 0, 1, 2, ...)
+    for (int n = sub; n < N; n += 8) {
         const int i = n * C + c;
         const float g = d_mean[i] * 0.25f + d_std[i] * (y4[(size_t)i * 4 + k] - y_mean[i]) / (3.f * y_std[i]);
         bs += g;
@@ -52,6 +54,14 @@ __global__ __launch_bounds__(256) void adain_style_bwd_kernel(const float* __res
         for (int j = 0; j < kMaxNc; ++j)
             if (j < nc) acc[j] += g * y[n * nc + j];
     }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+        bs += __shfl_xor(bs, m);
+#pragma unroll
+        for (int j = 0; j < kMaxNc; ++j)
+            if (j < nc) acc[j] += __shfl_xor(acc[j], m);
+    }
+    if (!valid || sub != 0) return;
     if (db) db[r] = accumulate ? db[r] + bs : bs;
 #pragma unroll
     for (int j = 0; j < kMaxNc; ++j)
@@ -72,7 +82,7 @@ extern "C" int wu_adain_style_fwd(const float* y, const float* w, const float* b
 extern "C" int wu_adain_style_bwd(const float* d_std, const float* d_mean, const float* y, const float* y4, const float* y_std,
                                   const float* y_mean, float* dw, float* db, int N, int C, int nc, int accumulate, void* stream) {
     WU_REQUIRE(d_std && d_mean && y && y4 && y_std && y_mean && dw && N > 0 && C > 0 && nc > 0 && nc <= kMaxNc, "adain_style_bwd: bad args");
-    hipLaunchKernelGGL(adain_style_bwd_kernel, dim3(cdiv(4 * C, 256)), dim3(256), 0, (hipStream_t)stream, d_std, d_mean, y, y4, y_std, y_mean,
+    hipLaunchKernelGGL(adain_style_bwd_kernel, dim3(cdiv(4 * C * 8, 256)), dim3(256), 0, (hipStream_t)stream, d_std, d_mean, y, y4, y_std, y_mean,
                        dw, db, N, C, nc, accumulate);
     WU_LAUNCH_CHECK("adain_style_bwd");
     return 0;
