@@ -28,15 +28,17 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__
 // =================================================================================================
 // MaxPool2d(2)   (cunet.py:27)
 // =================================================================================================
-template <typename T>
+// IDX = unsigned whenever the item count fits (the launchers choose): a 64-bit division / modulo is a ~100-instruction software
+// routine, and these kernels decompose their linear index with four of them per 16-byte item
+template <typename T, typename IDX>
 __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
                                     int N, int H, int W, int C) {
     constexpr int E = ElemTraits<T>::kPer16B;
     const int cpp = C / E, Ho = H / 2, Wo = W / 2;
-    const long long total = (long long)N * Ho * Wo * cpp;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const IDX total = (IDX)N * Ho * Wo * cpp;
+    for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
         const int ch = (int)(i % cpp);
-        long long p = i / cpp;
+        IDX p = i / cpp;
         const int ow = (int)(p % Wo); p /= Wo;
         const int oh = (int)(p % Ho);
         const int n = (int)(p / Ho);
@@ -58,16 +60,16 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restr
 
 // dx = dskip + route(dy): the window's first maximum (scan order (0,0),(0,1),(1,0),(1,1), strict >,
 // PyTorch's rule) receives dy.
-template <typename T>
+template <typename T, typename IDX>
 __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
                                     const T* __restrict__ dskip, int lddskip, T* __restrict__ dx, int lddx,
                                     int N, int H, int W, int C, int gate_act) {
     constexpr int E = ElemTraits<T>::kPer16B;
     const int cpp = C / E, Ho = H / 2, Wo = W / 2;
-    const long long total = (long long)N * Ho * Wo * cpp;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const IDX total = (IDX)N * Ho * Wo * cpp;
+    for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
         const int ch = (int)(i % cpp);
-        long long p = i / cpp;
+        IDX p = i / cpp;
         const int ow = (int)(p % Wo); p /= Wo;
         const int oh = (int)(p % Ho);
         const int n = (int)(p / Ho);
@@ -737,15 +739,15 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_apply_kernel(const T* __r
 
 // out = g * act'(y): the activation backward of autograd as ONE streaming pass, so that the data-gradient
 // and weight-gradient GEMMs both consume a pre-gated gradient (no gating inside their staging loops).
-template <typename T>
+template <typename T, typename IDX>
 __global__ void act_gate_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ y, int ldy, T* __restrict__ out, int ldo,
                                 long long npix, int C, int act) {
     constexpr int E = ElemTraits<T>::kPer16B;
     const int cpp = C / E;
-    const long long total = npix * cpp;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const IDX total = (IDX)npix * cpp;
+    for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
         const int ch = (int)(i % cpp);
-        const long long p = i / cpp;
+        const IDX p = i / cpp;
         const uint4 gv = *(const uint4*)(g + (size_t)p * ldg + ch * E);
         const uint4 yv = *(const uint4*)(y + (size_t)p * ldy + ch * E);
         *(uint4*)(out + (size_t)p * ldo + ch * E) = gate16<T>(gv, yv, act);
@@ -880,8 +882,12 @@ extern "C" int wu_maxpool2_fwd(const void* x, int ldx, void* y, int ldy, int N, 
     WU_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % (16 / esz) == 0 && C <= ldx && C <= ldy, "maxpool2_fwd: bad shape H=%d W=%d C=%d", H, W, C);
     WU_REQUIRE(ok16(x, ldx, esz) && ok16(y, ldy, esz), "maxpool2_fwd: alignment");
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / (16 / esz));
-    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                                         (const T*)x, ldx, (T*)y, ldy, N, H, W, C));
+    if (total < (1ll << 31))
+        DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2_fwd_kernel<T, unsigned>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)x, ldx, (T*)y, ldy, N, H, W, C));
+    else
+        DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2_fwd_kernel<T, long long>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)x, ldx, (T*)y, ldy, N, H, W, C));
     WU_LAUNCH_CHECK("maxpool2_fwd");
     return 0;
 }
@@ -892,8 +898,12 @@ extern "C" int wu_maxpool2_bwd(const void* x, int ldx, const void* dy, int lddy,
     WU_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % (16 / esz) == 0, "maxpool2_bwd: bad shape");
     WU_REQUIRE(ok16(x, ldx, esz) && ok16(dy, lddy, esz) && ok16(dx, lddx, esz) && (!dskip || ok16(dskip, lddskip, esz)), "maxpool2_bwd: alignment");
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / (16 / esz));
-    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                                         (const T*)x, ldx, (const T*)dy, lddy, (const T*)dskip, lddskip, (T*)dx, lddx, N, H, W, C, gate_act));
+    if (total < (1ll << 31))
+        DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2_bwd_kernel<T, unsigned>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)x, ldx, (const T*)dy, lddy, (const T*)dskip, lddskip, (T*)dx, lddx, N, H, W, C, gate_act));
+    else
+        DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2_bwd_kernel<T, long long>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)x, ldx, (const T*)dy, lddy, (const T*)dskip, lddskip, (T*)dx, lddx, N, H, W, C, gate_act));
     WU_LAUNCH_CHECK("maxpool2_bwd");
     return 0;
 }
@@ -1042,8 +1052,12 @@ extern "C" int wu_act_gate(const void* g, int ldg, const void* y, int ldy, void*
     WU_REQUIRE(C % (16 / esz) == 0 && ok16(g, ldg, esz) && ok16(y, ldy, esz) && ok16(out, ldo, esz), "act_gate: alignment");
     const long long npix = (long long)N * H * W;
     const long long total = npix * (C / (16 / esz));
-    DISPATCH_T(dtype, hipLaunchKernelGGL(act_gate_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
-                                         (const T*)g, ldg, (const T*)y, ldy, (T*)out, ldo, npix, C, act));
+    if (total < (1ll << 31))
+        DISPATCH_T(dtype, hipLaunchKernelGGL((act_gate_kernel<T, unsigned>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)g, ldg, (const T*)y, ldy, (T*)out, ldo, npix, C, act));
+    else
+        DISPATCH_T(dtype, hipLaunchKernelGGL((act_gate_kernel<T, long long>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)g, ldg, (const T*)y, ldy, (T*)out, ldo, npix, C, act));
     WU_LAUNCH_CHECK("act_gate");
     return 0;
 }

@@ -369,8 +369,9 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_mfma_kernel(const float*
             if (y) yv[k] = *(const uint4*)(y + (size_t)pc * ldy + s_ * 8);
         }
         const long long pc = min(base + tid, total - 1);
-        const long long rowi = pc / Wo;
-        const int ow = (int)(pc - rowi * Wo), n = (int)(rowi / Ho), oh = (int)(rowi - (long long)n * Ho);
+        // 32-bit decomposition (the host keeps N*Ho*Wo below 2^31 on this path: a 64-bit division is a ~100-instruction routine)
+        const unsigned pc32 = (unsigned)pc, rowi = pc32 / (unsigned)Wo;
+        const int ow = (int)(pc32 - rowi * (unsigned)Wo), n = (int)(rowi / (unsigned)Ho), oh = (int)(rowi - (unsigned)n * (unsigned)Ho);
         const float* xn = x + (size_t)n * 3 * H * W;
 #pragma unroll
         for (int k = 0; k < 27; ++k) {
@@ -682,10 +683,13 @@ __global__ __launch_bounds__(256) void conv1x1_tanh_fwd_kernel(const T* __restri
         for (int m = LP >> 1; m > 0; m >>= 1) {
             s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m);
         }
-        if (cl == 0 && pix < total) {
-            const long long n = pix / HW, p = pix - n * HW;
-            float* o = out + (size_t)n * 3 * HW + p;
-            o[0] = tanhf(s0 + b0); o[HW] = tanhf(s1 + b1); o[2 * (size_t)HW] = tanhf(s2 + b2);
+        if (cl < 3 && pix < total) {
+            // after the xor tree every lane of the pixel holds the three sums: lanes 0..2 finish one output channel each (one tanh
+            // per lane instead of three on lane 0); 32-bit index arithmetic (the host guarantees N*HW < 2^31: a 64-bit division is
+            // a ~100-instruction software routine)
+            const unsigned p32 = (unsigned)pix, n = p32 / (unsigned)HW, p = p32 - n * (unsigned)HW;
+            const float sk = cl == 0 ? s0 + b0 : (cl == 1 ? s1 + b1 : s2 + b2);
+            out[((size_t)n * 3 + cl) * HW + p] = tanhf(sk);
         }
     }
 }
@@ -712,7 +716,7 @@ __global__ __launch_bounds__(256) void conv1x1_tanh_bwd_kernel(const float* __re
     for (long long it = blockIdx.x; it < iters; it += gridDim.x) {
         const long long pix = it * ppi + tid / LP;
         if (pix >= total) continue;
-        const long long n = pix / HW, p = pix - n * HW;
+        const unsigned p32 = (unsigned)pix, n = p32 / (unsigned)HW, p = p32 - n * (unsigned)HW;      // N*HW < 2^31 (host check)
         const size_t o = (size_t)n * 3 * HW + p;
         float g[3];
 #pragma unroll
@@ -807,7 +811,7 @@ extern "C" int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy
     WU_REQUIRE(Cout > 0 && dw_oihw, "conv3x3_c3_wgrad: bad args");
     hipStream_t s = (hipStream_t)stream;
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-    const bool mfma_path = !dy_nchw && dtype == WU_BF16 && Cout == 64 && ((uintptr_t)dy % 16) == 0 && (lddy % 8) == 0 &&
+    const bool mfma_path = !dy_nchw && dtype == WU_BF16 && Cout == 64 && (long long)N * Ho * Wo < (1ll << 31) && ((uintptr_t)dy % 16) == 0 && (lddy % 8) == 0 &&
                            (!y || (((uintptr_t)y % 16) == 0 && (ldy_ % 8) == 0));
     // deterministic mode (every variant with Cout <= 64): a caller-owned slab receives the per-workgroup partials, thin_fold_kernel sums
     // them in workgroup order; without the slab the kernels fall back to fp32 atomics
@@ -880,6 +884,7 @@ extern "C" int wu_conv1x1_tanh_fwd(const void* x, int ldx, const float* w, const
     const int LP = Cin / E;
     WU_REQUIRE(Cin % E == 0 && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0, "conv1x1_tanh_fwd: Cin=%d unsupported", Cin);
     WU_REQUIRE(((uintptr_t)x % 16) == 0 && (ldx * esz) % 16 == 0 && bias, "conv1x1_tanh_fwd: alignment/bias");
+    WU_REQUIRE((long long)N * H * W < (1ll << 31), "conv1x1_tanh_fwd: N*H*W must stay below 2^31 (32-bit pixel arithmetic)");
     const int grid = grid_cap((long long)N * H * W, 256 / LP, 256 * 16);
     if (dtype == WU_BF16) hipLaunchKernelGGL(conv1x1_tanh_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, w, bias, out_nchw, N, H * W, Cin);
     else hipLaunchKernelGGL(conv1x1_tanh_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, w, bias, out_nchw, N, H * W, Cin);
@@ -894,6 +899,7 @@ extern "C" int wu_conv1x1_tanh_bwd(const float* dout_nchw, const float* out_nchw
     const int E = 16 / esz;
     const int LP = Cin / E;
     WU_REQUIRE(Cin == 64, "conv1x1_tanh_bwd: Cin must be 64 (got %d)", Cin);
+    WU_REQUIRE((long long)N * H * W < (1ll << 31), "conv1x1_tanh_bwd: N*H*W must stay below 2^31 (32-bit pixel arithmetic)");
     WU_REQUIRE(((uintptr_t)x % 16) == 0 && (ldx * esz) % 16 == 0 && ((uintptr_t)dx % 16) == 0 && (lddx * esz) % 16 == 0, "conv1x1_tanh_bwd: alignment");
     hipStream_t s = (hipStream_t)stream;
     // deterministic mode (caller-owned slab for the per-workgroup partials); otherwise fp32 atomics across workgroups
