@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void image_geometry_kernel(const uint8_t* __re
                                                              int N, int S, int ksize, int rot_first) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)N * S * S) return;
-    const int ox = (int)(i % S), oy = (int)((i / S) % S), n = (int)(i / ((long long)S * S));
+    const unsigned i32 = (unsigned)i, row = i32 / (unsigned)S;              // N*S*S < 2^31 (host check)
+    const int ox = (int)(i32 - row * (unsigned)S), n = (int)(row / (unsigned)S), oy = (int)(row - (unsigned)n * (unsigned)S);
     const ImgGeo g = geo[n];
     const uint8_t* im = src + g.src_off;
     int px = g.flip ? S - 1 - ox : ox, py = oy;               // F.hflip is the last geometric op in both pipelines
@@ -198,6 +199,7 @@ extern "C" int wu_image_geometry(const uint8_t* src, const void* geo, void* work
     WU_REQUIRE(src && geo && workspace && (dst_u8 || dst_nchw), "image_geometry: null argument");
     WU_REQUIRE(N > 0 && S > 0 && S < 32768 && ksize >= 3 && ksize <= 4099, "image_geometry: bad shape N=%d S=%d ksize=%d", N, S, ksize);
     WU_REQUIRE(workspace_bytes >= wu_image_workspace_bytes(N, S, ksize), "image_geometry: workspace too small");
+    WU_REQUIRE((long long)N * S * S < (1ll << 31), "image_geometry: N*S*S must stay below 2^31");
     hipStream_t s = (hipStream_t)stream;
     int* bounds = (int*)workspace;
     int* coeffs = bounds + (size_t)N * 2 * S * 2;

@@ -298,10 +298,8 @@ __global__ __launch_bounds__(256) void stem7x7_dgrad_kernel(const T* __restrict_
     const int sub = tid & 7;                                           // channel octet
     const long long total = (long long)N * H * W;
     for (long long pix = (long long)blockIdx.x * 32 + (tid >> 3); pix < total; pix += (long long)gridDim.x * 32) {
-        const int iw = (int)(pix % W);
-        const long long t = pix / W;
-        const int ih = (int)(t % H);
-        const int n = (int)(t / H);
+        const unsigned p32 = (unsigned)pix, t = p32 / (unsigned)W;         // N*H*W < 2^31 (host check): no 64-bit division per pixel
+        const int iw = (int)(p32 - t * (unsigned)W), n = (int)(t / (unsigned)H), ih = (int)(t - (unsigned)n * (unsigned)H);
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
         // kh must have the parity of ih + 3 (so that ih + 3 - kh = 2 * oh)
         for (int kh = (ih + 3) & 1; kh < 7; kh += 2) {
@@ -499,6 +497,7 @@ extern "C" int wu_stem7x7_dgrad(const void* dy, int lddy, const float* w_oihw, f
     const int esz = dtype == WU_BF16 ? 2 : 4;
     WU_REQUIRE(N > 0 && H >= 7 && W >= 7 && dy && w_oihw && dx_nchw, "stem7x7_dgrad: bad shape");
     WU_REQUIRE(lddy >= 64 && (lddy * esz) % 16 == 0 && al16(dy), "stem7x7_dgrad: bad ld / alignment");
+    WU_REQUIRE((long long)N * H * W < (1ll << 31), "stem7x7_dgrad: N*H*W must stay below 2^31");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long pixels = (long long)N * H * W;
     DISPATCH_T(dtype, hipLaunchKernelGGL(stem7x7_dgrad_kernel<T>, dim3(grid_cap(pixels, 32, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
