@@ -70,13 +70,15 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(const float* __rest
 // kernel.  Accumulators are transposed (lane owns 4 consecutive channels of its pixel); the epilogue transposes through a
 // wave-private LDS patch (no barrier) so the stores cover whole pixel rows.  The VALU form above needs
 // 1728 fp32 FMAs per pixel (fp32 VALU peak = 1/16 of the bf16 matrix rate); this one is bound by the 268 MB it writes.
-template <int STRIDE, int ACT>
-__global__ __launch_bounds__(256) void conv3x3_c3_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int STRIDE, int ACT, bool FULL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv3x3_c3_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, const float* __restrict__ inv_sigma,
                                                                   bf16_t* __restrict__ y, int ldy, int N, int H, int W) {
     __shared__ __attribute__((aligned(16))) char tile[4 * 32 * 144];
+    __shared__ __attribute__((aligned(16))) float bias_s[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
     const float sg = inv_sigma ? *inv_sigma : 1.f;
+    if (threadIdx.x < 64) bias_s[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
     // weights as the MFMA A operand: row = co = 32 m + l31, k = 16 ks + 8 lh + j
     uint4 wf[2][2];
 #pragma unroll
@@ -91,48 +93,63 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_mfma_kernel(const float* _
             }
             wf[m][ks] = pack16<bf16_t>(f);
         }
-    // this lane's 16 K slots: element offset relative to the centre input pixel, and (dh, dw) for the border test
+    // this lane's 16 K slots: k = 16 (t >> 3) + 8 lh + (t & 7) -> channel byte offset ci * H * W * 4 (one register per slot);
+    // the (kh, kw) of a slot are compile-time constants per half-wave.  The five padding slots (k >= 27) point at the centre
+    // pixel of channel 0: their weights are zero and that pixel is in the patch anyway.
     const int HW = H * W;
-    int kch[16], kdh[16], kdw[16];
+    unsigned chan[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const int k = 16 * (t >> 3) + 8 * lh + (t & 7);
-        const int ci = k < 27 ? k / 9 : 0, r = k - (k / 9) * 9, kh = r / 3, kw = r - kh * 3;
-        kch[t] = ci * HW;
-        kdh[t] = k < 27 ? kh - 1 : (1 << 20);          // an invalid slot never passes the row test
-        kdw[t] = kw - 1;
+        chan[t] = k < 27 ? (unsigned)((k / 9) * HW) * 4u : 0u;
     }
-    float4 bq[2][4];       // bias of channels 32 m + 8 g + 4 lh + (0..3)
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bq[m][g] = bias ? *(const float4*)(bias + 32 * m + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();       // bias_s
 
     const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
     const int total = N * Ho * Wo;                 // < 2^31 (checked by the host): 32-bit index arithmetic
     const int nblk = (total + 31) / 32;
-    for (int blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4) {
+    const int bstep = gridDim.x * 4;
+    // The image is read through a buffer descriptor (x is < 2^30 bytes, host check): a tap outside the image gets a byte
+    // offset >= 2^30 -- out of range, the load returns 0 -- so the padding needs neither clamped coordinates nor a select
+    // afterwards.  Per block a lane computes 3 row terms and 3 column terms; a slot's offset is one v_add3 of the two terms
+    // picked by half-wave and the slot's channel offset (the first version spent ~20 VALU instructions per slot on clamps,
+    // 64-bit addresses and masks and was VALU-bound at 107 us).
+    // The patch of block i + 1 is requested BEFORE block i is multiplied and stored -- with three waves per SIMD nothing else
+    // covers the ~2 us round trip -- from inline asm, retired by ONE counted wait at the end of the iteration: vmcnt(4) leaves
+    // this iteration's four stores in flight (left to the compiler, the loop header waits vmcnt(0), write acknowledgements
+    // included).
+    const wu_rsrc_t rs = wu_make_rsrc(x, (unsigned)((size_t)N * 3 * HW * 4));
+    auto gather = [&](int blk, float (&v)[16]) __attribute__((always_inline)) {
         const int pix = blk * 32 + l31;
-        const bool ok = pix < total;
-        const int pc = ok ? pix : total - 1;
+        const int pc = min(pix, total - 1);
         const int rowi = pc / Wo, ow = pc - rowi * Wo, n = rowi / Ho, oh = rowi - n * Ho;
-        const int ih0 = oh * STRIDE, iw0 = ow * STRIDE;
-        const float* xn = x + (size_t)n * 3 * HW;
-        // 16 UNCONDITIONAL loads from clamped coordinates, zeroed afterwards (a conditional load compiles to a branch with its
-        // own s_waitcnt: 16 serialized round trips per iteration)
-        float v[16];
+        const int ih0 = oh * STRIDE - 1, iw0 = ow * STRIDE - 1;
+        const unsigned nb = (unsigned)(n * 3 * HW) * 4u;
+        unsigned rowb[3], colb[3];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int ih = ih0 + kdh[t], iw = iw0 + kdw[t];
-            const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
-            v[t] = xn[kch[t] + ihc * W + iwc];
+        for (int d = 0; d < 3; ++d) {
+            rowb[d] = (unsigned)(ih0 + d) < (unsigned)H ? nb + (unsigned)((ih0 + d) * W) * 4u : 0x40000000u;
+            colb[d] = (unsigned)(iw0 + d) < (unsigned)W ? (unsigned)(iw0 + d) * 4u : 0x80000000u;
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const int ih = ih0 + kdh[t], iw = iw0 + kdw[t];
-            v[t] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? v[t] : 0.f;
+            const int kA = 16 * (t >> 3) + (t & 7), kB = kA + 8;
+            const int rA = kA < 27 ? kA % 9 : 4, rB = kB < 27 ? kB % 9 : 4;
+            const unsigned off = (lh ? rowb[rB / 3] : rowb[rA / 3]) + (lh ? colb[rB % 3] : colb[rA % 3]) + chan[t];
+            asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=&v"(v[t]) : "v"(off), "s"(rs) : "memory");
         }
-        const uint4 pf0 = pack16<bf16_t>(v), pf1 = pack16<bf16_t>(v + 8);
+    };
+    float vn[16];
+    int blk = blockIdx.x * 4 + wave;
+#define WU_V16(v) "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), \
+                  "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+    if (blk < nblk) {
+        gather(blk, vn);
+        asm volatile("s_waitcnt vmcnt(0)" : WU_V16(vn) : : "memory");
+    }
+    for (; blk < nblk; blk += bstep) {
+        const uint4 pf0 = pack16<bf16_t>(vn), pf1 = pack16<bf16_t>(vn + 8);
+        gather(min(blk + bstep, nblk - 1), vn);      // past the end: a harmless re-read of the last block
         f32x16_t acc[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -149,7 +166,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_mfma_kernel(const float* _
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 bv = bq[m][g];
+                const float4 bv = *(const float4*)(bias_s + 32 * m + 8 * g + 4 * lh);
                 const int r0 = 4 * g;
                 const uint32_t lo = pack_bf16x2(act_apply(acc[m][r0 + 0] + bv.x, ACT), act_apply(acc[m][r0 + 1] + bv.y, ACT));
                 const uint32_t hi = pack_bf16x2(act_apply(acc[m][r0 + 2] + bv.z, ACT), act_apply(acc[m][r0 + 3] + bv.w, ACT));
@@ -162,10 +179,16 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_mfma_kernel(const float* _
             const int r = 8 * k + (lane >> 3), sl = lane & 7;
             const int p2 = blk * 32 + r;
             const uint4 v4 = *(const uint4*)(tp + r * 144 + sl * 16);
-            if (p2 < total) *(uint4*)(y + (size_t)p2 * ldy + sl * 8) = v4;
+            // FULL (total % 32 == 0): unconditional stores.  Behind a branch the compiler cannot count them and waits vmcnt(0)
+            // -- their write acknowledgements -- before it touches the prefetched patch at the top of the next iteration.
+            if (FULL || p2 < total) *(uint4*)(y + (size_t)p2 * ldy + sl * 8) = v4;
         }
         __builtin_amdgcn_wave_barrier();
+        // the next block's patch has landed (the registers named here are exactly the asm loads' destinations)
+        if (FULL) asm volatile("s_waitcnt vmcnt(4)" : WU_V16(vn) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : WU_V16(vn) : : "memory");
     }
+#undef WU_V16
 }
 
 // NHWC-output form of the conv above (Cout = 64), production path.  One thread = one output pixel with its 27 inputs in
@@ -329,7 +352,7 @@ __global__ __launch_bounds__(256) void thin_fold_kernel(const float* __restrict_
 // 27-element patch row (bf16, padded to 32) are staged in LDS; both MFMA operands have the pixel (K) as their
 // slow index, so fragments come through ds_read_b64_tr_b16 as in conv3x3_wgrad.  4 waves split the 16 K-steps;
 // accumulators persist over a grid-stride loop of tiles, then one LDS reduction + fp32 atomics per workgroup.
-template <int STRIDE>
+template <int STRIDE, bool GATE>
 __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, int lddy,
                                                                     const bf16_t* __restrict__ y, int ldy, int act,
                                                                     float* __restrict__ dw, float* __restrict__ dbias,
@@ -358,6 +381,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_mfma_kernel(const float*
     float pv[32];
 #pragma unroll
     for (int k = 27; k < 32; ++k) pv[k] = 0.f;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((size_t)N * 3 * H * W * 4), 0x00020000);
     auto fetch = [&](long long tile) __attribute__((always_inline)) {
         const long long base = tile * 256;
 #pragma unroll
@@ -366,19 +390,31 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_mfma_kernel(const float*
             const int r = item >> 3, s_ = item & 7;
             const long long pc = min(base + r, total - 1);
             dv[k] = *(const uint4*)(dy + (size_t)pc * lddy + s_ * 8);
-            if (y) yv[k] = *(const uint4*)(y + (size_t)pc * ldy + s_ * 8);
+            if (GATE) yv[k] = *(const uint4*)(y + (size_t)pc * ldy + s_ * 8);
         }
         const long long pc = min(base + tid, total - 1);
         // 32-bit decomposition (the host keeps N*Ho*Wo below 2^31 on this path: a 64-bit division is a ~100-instruction routine)
         const unsigned pc32 = (unsigned)pc, rowi = pc32 / (unsigned)Wo;
         const int ow = (int)(pc32 - rowi * (unsigned)Wo), n = (int)(rowi / (unsigned)Ho), oh = (int)(rowi - (unsigned)n * (unsigned)Ho);
-        const float* xn = x + (size_t)n * 3 * H * W;
+        // the image goes through a buffer descriptor (< 2^30 bytes, host check): a tap outside the image -- or a pixel past the
+        // end -- gets an out-of-range offset and loads 0, so the 27 offsets are one add each on top of 3 row + 3 column terms
+        // (clamped 64-bit addresses + selects were ~20 VALU instructions per tap)
+        const bool pok = base + tid < total;
+        const unsigned nb = (unsigned)(n * 3 * H * W) * 4u, hw4 = (unsigned)(H * W) * 4u;
+        unsigned rc[9];
 #pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            const int ci = k / 9, t = k % 9, ih = oh * STRIDE + t / 3 - 1, iw = ow * STRIDE + t % 3 - 1;
-            const float v = xn[((size_t)ci * H + min(max(ih, 0), H - 1)) * W + min(max(iw, 0), W - 1)];
-            pv[k] = (base + tid < total && ih >= 0 && ih < H && iw >= 0 && iw < W) ? v : 0.f;
+        for (int d = 0; d < 3; ++d) {
+            const int ih = oh * STRIDE + d - 1;
+            const unsigned rowb = (pok && (unsigned)ih < (unsigned)H) ? nb + (unsigned)(ih * W) * 4u : 0x40000000u;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const int iw = ow * STRIDE + e - 1;
+                rc[3 * d + e] = rowb + ((unsigned)iw < (unsigned)W ? (unsigned)iw * 4u : 0x80000000u);
+            }
         }
+#pragma unroll
+        for (int k = 0; k < 27; ++k)
+            pv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, rc[k % 9] + (unsigned)(k / 9) * hw4, 0, 0));
     };
     auto stage = [&](long long tile) __attribute__((always_inline)) {
         const long long base = tile * 256;
@@ -387,7 +423,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_mfma_kernel(const float*
             const int item = tid + 256 * k;
             const int r = item >> 3, s_ = item & 7;
             uint4 v = dv[k];
-            if (y) v = gate16<bf16_t>(v, yv[k], act);
+            if (GATE) v = gate16<bf16_t>(v, yv[k], act);
             if (base + r >= total) v = make_uint4(0, 0, 0, 0);
             *(uint4*)(dy_lds + r * 128 + ((s_ * 16) ^ (((r >> 1) & 1) << 6))) = v;
         }
@@ -781,12 +817,13 @@ extern "C" int wu_conv3x3_c3_fwd(const float* x_nchw, const float* w_oihw, const
     const int grid_l = grid_cap((long long)N * Ho * Wo, 256, 256 * 8);
     // fp32 path: the LDS-broadcast one-thread-per-pixel kernel (239 us at B=32 256x256 in bf16 storage; the scalar-weight /
     // transposed-store variant conv3x3_c3_fwd_rows_kernel measured 326 us and is kept selectable for A/B work)
-#define C3_MFMA_A(ST, A) hipLaunchKernelGGL((conv3x3_c3_fwd_mfma_kernel<ST, A>), dim3(grid_m), dim3(256), 0, s, x_nchw, w_oihw, bias, inv_sigma, (bf16_t*)y, ldy, N, H, W)
+#define C3_MFMA_F(ST, A, F) hipLaunchKernelGGL((conv3x3_c3_fwd_mfma_kernel<ST, A, F>), dim3(grid_m), dim3(256), 0, s, x_nchw, w_oihw, bias, inv_sigma, (bf16_t*)y, ldy, N, H, W)
+#define C3_MFMA_A(ST, A) do { if (((long long)N * Ho * Wo) % 32 == 0) C3_MFMA_F(ST, A, true); else C3_MFMA_F(ST, A, false); } while (0)
 #define C3_MFMA(ST) do { if (act == WU_ACT_RELU) C3_MFMA_A(ST, WU_ACT_RELU); else if (act == WU_ACT_LEAKY) C3_MFMA_A(ST, WU_ACT_LEAKY); else C3_MFMA_A(ST, WU_ACT_NONE); } while (0)
     const int grid_m = grid_cap((long long)N * Ho * Wo, 128, 256 * 16);
     // option 5: 0 = bf16 on the matrix cores (default), 1 = scalar-weight rows kernel, 2 = one-thread-per-pixel VALU kernel
     if (out_nchw) C3_LAUNCH(float, 3, 1, true);
-    else if (dtype == WU_BF16 && g_wu_opt[WU_OPT_C3_ROWS] == 0 && (!bias || ((uintptr_t)bias % 16) == 0) && (long long)N * Ho * Wo < (1ll << 31) - 64) { if (stride == 1) C3_MFMA(1); else C3_MFMA(2); }
+    else if (dtype == WU_BF16 && g_wu_opt[WU_OPT_C3_ROWS] == 0 && (!bias || ((uintptr_t)bias % 16) == 0) && (long long)N * Ho * Wo < (1ll << 31) - 64 && (long long)N * 3 * H * W < (1ll << 28)) { if (stride == 1) C3_MFMA(1); else C3_MFMA(2); }
     else if (g_wu_opt[WU_OPT_C3_ROWS] == 1) {
         if (dtype == WU_BF16) { if (stride == 1) C3_LANES(bf16_t, 1); else C3_LANES(bf16_t, 2); }
         else { if (stride == 1) C3_LANES(float, 1); else C3_LANES(float, 2); }
@@ -794,6 +831,7 @@ extern "C" int wu_conv3x3_c3_fwd(const float* x_nchw, const float* w_oihw, const
     else { if (stride == 1) C3_LAUNCH(float, 64, 1, false); else C3_LAUNCH(float, 64, 2, false); }
 #undef C3_MFMA
 #undef C3_MFMA_A
+#undef C3_MFMA_F
 #undef C3_LANES
 #undef C3_LANES_A
 #undef C3_LAUNCH_A
@@ -811,7 +849,7 @@ extern "C" int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy
     WU_REQUIRE(Cout > 0 && dw_oihw, "conv3x3_c3_wgrad: bad args");
     hipStream_t s = (hipStream_t)stream;
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-    const bool mfma_path = !dy_nchw && dtype == WU_BF16 && Cout == 64 && (long long)N * Ho * Wo < (1ll << 31) && ((uintptr_t)dy % 16) == 0 && (lddy % 8) == 0 &&
+    const bool mfma_path = !dy_nchw && dtype == WU_BF16 && Cout == 64 && (long long)N * Ho * Wo < (1ll << 31) && (long long)N * 3 * H * W < (1ll << 28) && ((uintptr_t)dy % 16) == 0 && (lddy % 8) == 0 &&
                            (!y || (((uintptr_t)y % 16) == 0 && (ldy_ % 8) == 0));
     // deterministic mode (every variant with Cout <= 64): a caller-owned slab receives the per-workgroup partials, thin_fold_kernel sums
     // them in workgroup order; without the slab the kernels fall back to fp32 atomics
@@ -825,8 +863,10 @@ extern "C" int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy
     if (mfma_path) {
         const long long ntiles = ((long long)N * Ho * Wo + 255) / 256;
         const int g = (int)(ntiles < kThinMaxBlocks ? ntiles : kThinMaxBlocks);
-        if (stride == 1) hipLaunchKernelGGL(conv3x3_c3_wgrad_mfma_kernel<1>, dim3(g), dim3(256), 0, s, x_nchw, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy_, act, dw_oihw, dbias, part, N, H, W);
-        else hipLaunchKernelGGL(conv3x3_c3_wgrad_mfma_kernel<2>, dim3(g), dim3(256), 0, s, x_nchw, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy_, act, dw_oihw, dbias, part, N, H, W);
+#define C3WM(ST, G) hipLaunchKernelGGL((conv3x3_c3_wgrad_mfma_kernel<ST, G>), dim3(g), dim3(256), 0, s, x_nchw, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy_, act, dw_oihw, dbias, part, N, H, W)
+        if (stride == 1) { if (y) C3WM(1, true); else C3WM(1, false); }
+        else { if (y) C3WM(2, true); else C3WM(2, false); }
+#undef C3WM
         if (part) hipLaunchKernelGGL(thin_fold_kernel, dim3(cdiv(kC3Slab, 8)), dim3(256), 0, s, part, g, kC3Slab, dw_oihw, 1728, dbias, 64, accumulate);
         WU_LAUNCH_CHECK("conv3x3_c3_wgrad_mfma");
         return 0;
