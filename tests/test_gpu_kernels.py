@@ -176,7 +176,8 @@ def test_conv3x3_gated_abi_paths(p, act):
 
 
 @pytest.mark.parametrize("p", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 64, 16, 24, 1, 1, False), (2, 64, 17, 19, 2, 2, False), (2, 3, 12, 20, 1, 0, True)])
+@pytest.mark.parametrize("cfg", [(2, 64, 16, 24, 1, 1, False), (2, 64, 17, 19, 2, 2, False), (2, 3, 12, 20, 1, 0, True),
+                                 (2, 64, 40, 72, 2, 2, False), (1, 64, 34, 130, 2, 0, False)])
 def test_conv3x3_c3(p, cfg):
     """3-input-channel conv read from the NCHW fp32 image (cunet.py:45, disc.py:28): fwd, wgrad, dgrad."""
     from wu import functional as WF

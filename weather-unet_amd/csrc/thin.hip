@@ -626,6 +626,101 @@ __global__ __launch_bounds__(256) void conv3x3_c3_dgrad_nhwc_kernel(const T* __r
     }
 }
 
+// bf16 production path of the stride-2 data gradient above (disc.conv1[1], 64 channels -> the 3-channel image), on the matrix
+// cores.  Per OUTPUT pixel q the 27 products P[k][q] = sum_co W[co][k] * dY'[q][co] are one 32 x 32 x 64 MFMA block per 32
+// pixels (k = ci*9 + kh*3 + kw, padded to 32); an input pixel then sums the 1, 2 or 4 entries of P that reach it (stride 2: the
+// taps of matching parity), in a fixed order -- no atomics.  A workgroup takes an 8 x 32 tile of output pixels plus one halo row
+// and column (the odd input rows / columns at the far edge read them), parks P in LDS as [k][q] and writes the 16 x 64 input
+// pixels of its tile with row-contiguous stores.  The VALU formulation above spends ~400 instructions per 8 input pixels (LDS
+// weight reads, shuffles, 64-bit addresses): 402 us at B = 32 256x256 against ~100 MB of traffic.
+template <bool GATE>
+__global__ __launch_bounds__(256) void conv3x3_c3_dgrad_s2_mfma_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ y, int ldy,
+                                                                       int act, const float* __restrict__ w, const float* __restrict__ inv_sigma,
+                                                                       float* __restrict__ dx, int H, int W, int tiles_x, int tiles_y, int accumulate) {
+    constexpr int TH = 8, TW = 32, QW = TW + 1, QN = (TH + 1) * QW, NB = (QN + 31) / 32, PS = NB * 32 + 1;
+    __shared__ float P[27 * PS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const float sg = inv_sigma ? *inv_sigma : 1.f;
+    // weights as the MFMA A operand: row = k = l31 (27 real rows), reduction index co = 16 ks + 8 lh + j
+    uint4 wf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = l31 < 27 ? w[(16 * ks + 8 * lh + j) * 27 + l31] * sg : 0.f;
+        wf[ks] = pack16<bf16_t>(f);
+    }
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y, n = t / tiles_y;
+    const int oh0 = ty * TH, ow0 = tx * TW;
+    // ---- P = W^T dY' for the (TH + 1) x (TW + 1) output pixels, 32 at a time (blocks wave, wave + 4, wave + 8) ----
+    constexpr int MAXB = (NB + 3) / 4;
+    uint4 av[MAXB][4];
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int b = wave + 4 * i;
+        const int q = 32 * b + l31, r = q / QW, c = q - r * QW;
+        const int oh = oh0 + r, ow = ow0 + c;
+        const bool ok = b < NB && q < QN && oh < Ho && ow < Wo;
+        const size_t op = ((size_t)n * Ho + min(oh, Ho - 1)) * Wo + min(ow, Wo - 1);
+        const unsigned m = ok ? 0xffffffffu : 0u;       // lane mask instead of a 128-bit select (which goes through scratch)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 v = *(const uint4*)(dy + op * lddy + 16 * ks + 8 * lh);
+            if (GATE) v = gate16<bf16_t>(v, *(const uint4*)(y + op * ldy + 16 * ks + 8 * lh), act);
+            av[i][ks] = make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int b = wave + 4 * i;
+        if (b >= NB) break;
+        f32x16_t acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[ks]), __builtin_bit_cast(bf16x8_t, av[i][ks]), acc, 0, 0, 0);
+        // lane (pixel l31, half lh) holds rows k = 8 g + 4 lh + e of its pixel's column
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 8 * g + 4 * lh + e;
+                if (k < 27) P[k * PS + 32 * b + l31] = acc[4 * g + e];
+            }
+    }
+    __syncthreads();
+    // ---- input pixels (2 oh0 + row, 2 ow0 + col), row < 16, col < 64: taps of matching parity, summed in (kh, kw) order ----
+    const int col = tid & 63, iw = 2 * ow0 + col;
+    const bool pw = col & 1;
+    const int kwA = pw ? 0 : 1, cA = (col + 1) >> 1, cB = col >> 1;
+    const size_t hw = (size_t)H * W;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (tid >> 6) + 4 * j, ih = 2 * oh0 + row;
+        const bool ph = row & 1;
+        const int khA = ph ? 0 : 1, rA = (row + 1) >> 1, rB = row >> 1;
+        if (ih < H && iw < W) {
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float* pk = P + ci * 9 * PS;
+                float sacc = pk[(khA * 3 + kwA) * PS + rA * QW + cA];
+                const float v1 = pk[(khA * 3 + 2) * PS + rA * QW + cB];
+                const float v2 = pk[(6 + kwA) * PS + rB * QW + cA];
+                const float v3 = pk[8 * PS + rB * QW + cB];
+                sacc += pw ? v1 : 0.f;
+                sacc += ph ? v2 : 0.f;
+                sacc += (ph && pw) ? v3 : 0.f;
+                float* o = dx + ((size_t)n * 3 + ci) * hw + (size_t)ih * W + iw;
+                *o = accumulate ? *o + sacc : sacc;
+            }
+        }
+    }
+}
+
 // Weight gradient of the 3->3 image-layout conv (disc.conv1[0]: NCHW fp32 dy, Cout <= 4): one thread per output
 // pixel accumulates all Cout*27 products in registers over a grid-stride loop; wave shuffle + LDS reduce; atomics.
 template <int STRIDE>
@@ -692,40 +787,68 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_small_kernel(const float
 // conv_last (1x1, Cin -> 3) + tanh.  LP lanes share one pixel (16 B of channels each): a wave load is
 // 64/LP full pixel rows; the three dot products are finished with xor-shuffles.
 // ---------------------------------------------------------------------------------------------------
-template <typename T>
+// sum over the LP (power of two) consecutive lanes that share a pixel; every lane of the group ends with the total.
+// DPP lane moves folded into the adds (no LDS crossbar): xor 1, xor 2, then mirrors (lane i <-> 7 - i, i <-> 15 - i), which
+// pair equal-valued groups just like xor 4 / xor 8 would.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_group_sum(float v, int LP) {
+    if (LP >= 2) v += dpp_mov<0xB1>(v);         // quad_perm [1,0,3,2]
+    if (LP >= 4) v += dpp_mov<0x4E>(v);         // quad_perm [2,3,0,1]
+    if (LP >= 8) v += dpp_mov<0x141>(v);        // row_half_mirror
+    if (LP >= 16) v += dpp_mov<0x140>(v);       // row_mirror
+    if (LP >= 32) v += __shfl_xor(v, 16);
+    if (LP >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+// tanh(s) = 1 - 2 / (exp(2 s) + 1) on the hardware exp2 / rcp units: absolute error ~2e-7 (the library tanhf is ~40 VALU
+// instructions, which made the forward head VALU-bound); saturates correctly (exp -> inf gives 1, exp -> 0 gives -1)
+__device__ __forceinline__ float fast_tanh(float s) {
+    const float e = __builtin_amdgcn_exp2f(s * 2.885390081777927f);       // exp(2 s) = 2^(2 s log2 e)
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
+
+// grid: x = pixel groups of one image (strided), y = image.  32-bit index arithmetic throughout (the host checks H*W*ldx < 2^31).
+// LPT: lanes per pixel when known at compile time (Cin = 64: 8 for bf16, 16 for fp32), 0 = Cin / E at run time
+template <typename T, int LPT>
 __global__ __launch_bounds__(256) void conv1x1_tanh_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ out,
-                                                               int N, int HW, int Cin) {
+                                                               int HW, int Cin) {
     constexpr int E = ElemTraits<T>::kPer16B;
-    const int LP = Cin / E;                      // lanes per pixel (8 for bf16/64ch, 16 for fp32/64ch)
-    const int tid = threadIdx.x, cl = tid % LP;
+    const int LP = LPT ? LPT : Cin / E;
+    const int tid = threadIdx.x, cl = tid & (LP - 1), pl = tid / LP;
     float wr[3][E];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int e = 0; e < E; ++e) wr[k][e] = w[k * Cin + cl * E + e];
-    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
+    const float bk = cl < 3 ? bias[cl] : 0.f;
     const int ppi = 256 / LP;
-    const long long total = (long long)N * HW;
-    const long long iters = (total + ppi - 1) / ppi;
-    for (long long it = blockIdx.x; it < iters; it += gridDim.x) {
-        const long long pix = it * ppi + tid / LP;
-        float v[E], s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        if (pix < total) {
-            unpack16<T>(*(const uint4*)(x + (size_t)pix * ldx + cl * E), v);
+    const T* xn = x + (size_t)blockIdx.y * HW * ldx;
+    float* on = out + (size_t)blockIdx.y * 3 * HW + (cl < 3 ? cl : 0) * HW;
+    // two pixel groups per iteration: two independent 16-byte loads in flight per lane
+    for (int p0 = blockIdx.x * 2 * ppi; p0 < HW; p0 += gridDim.x * 2 * ppi) {
+        const int pa = p0 + pl, pb = pa + ppi;
+        // unconditional loads from clamped pixels (a conditional load is a branch with its own wait); the tail's results are dropped
+        const uint4 ra = *(const uint4*)(xn + (unsigned)(min(pa, HW - 1) * ldx + cl * E));
+        const uint4 rb = *(const uint4*)(xn + (unsigned)(min(pb, HW - 1) * ldx + cl * E));
+        float va[E], vb[E], sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
+        unpack16<T>(ra, va);
+        unpack16<T>(rb, vb);
 #pragma unroll
-            for (int e = 0; e < E; ++e) { s0 += v[e] * wr[0][e]; s1 += v[e] * wr[1][e]; s2 += v[e] * wr[2][e]; }
-        }
-        for (int m = LP >> 1; m > 0; m >>= 1) {
-            s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m);
-        }
-        if (cl < 3 && pix < total) {
-            // after the xor tree every lane of the pixel holds the three sums: lanes 0..2 finish one output channel each (one tanh
-            // per lane instead of three on lane 0); 32-bit index arithmetic (the host guarantees N*HW < 2^31: a 64-bit division is
-            // a ~100-instruction software routine)
-            const unsigned p32 = (unsigned)pix, n = p32 / (unsigned)HW, p = p32 - n * (unsigned)HW;
-            const float sk = cl == 0 ? s0 + b0 : (cl == 1 ? s1 + b1 : s2 + b2);
-            out[((size_t)n * 3 + cl) * HW + p] = tanhf(sk);
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < E; ++e) { sa[k] += va[e] * wr[k][e]; sb[k] += vb[e] * wr[k][e]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { sa[k] = lane_group_sum(sa[k], LP); sb[k] = lane_group_sum(sb[k], LP); }
+        // every lane of the pixel holds the three sums: lanes 0..2 finish one output channel each
+        const float ta = fast_tanh((cl == 0 ? sa[0] : (cl == 1 ? sa[1] : sa[2])) + bk);
+        const float tb = fast_tanh((cl == 0 ? sb[0] : (cl == 1 ? sb[1] : sb[2])) + bk);
+        if (cl < 3) {
+            if (pa < HW) on[pa] = ta;
+            if (pb < HW) on[pb] = tb;
         }
     }
 }
@@ -898,6 +1021,19 @@ extern "C" int wu_conv3x3_c3_dgrad(const void* dy, int lddy, int dy_nchw, const 
     const size_t lds = (size_t)27 * Cout * sizeof(float);
     const int esz_ = dtype == WU_BF16 ? 2 : 4;
     const int lp_ = dy_nchw ? 0 : Cout / (16 / esz_);
+    if (!dy_nchw && dtype == WU_BF16 && stride == 2 && Cout == 64 && ((uintptr_t)dy % 16) == 0 && (lddy % 8) == 0 &&
+        (!y || (((uintptr_t)y % 16) == 0 && (ldy_ % 8) == 0))) {
+        const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+        const int tiles_x = cdiv(Wo, 32), tiles_y = cdiv(Ho, 8);
+        const long long nwg = (long long)N * tiles_x * tiles_y;
+        if (nwg < (1ll << 31)) {
+#define C3DM(G) hipLaunchKernelGGL((conv3x3_c3_dgrad_s2_mfma_kernel<G>), dim3((unsigned)nwg), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy_, act, w_oihw, inv_sigma, dx_nchw, H, W, tiles_x, tiles_y, accumulate)
+            if (y) C3DM(true); else C3DM(false);
+#undef C3DM
+            WU_LAUNCH_CHECK("conv3x3_c3_dgrad_s2_mfma");
+            return 0;
+        }
+    }
     if (!dy_nchw && (long long)N * H * W < (1ll << 32) && Cout % (16 / esz_) == 0 && lp_ >= 1 && lp_ <= 64 && (lp_ & (lp_ - 1)) == 0 && ((uintptr_t)dy % 16) == 0 && (lddy * esz_) % 16 == 0 &&
         (!y || (((uintptr_t)y % 16) == 0 && (ldy_ * esz_) % 16 == 0))) {
         const int g = grid_cap((long long)N * H * W, 256 / lp_, 256 * 16);
@@ -925,9 +1061,14 @@ extern "C" int wu_conv1x1_tanh_fwd(const void* x, int ldx, const float* w, const
     WU_REQUIRE(Cin % E == 0 && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0, "conv1x1_tanh_fwd: Cin=%d unsupported", Cin);
     WU_REQUIRE(((uintptr_t)x % 16) == 0 && (ldx * esz) % 16 == 0 && bias, "conv1x1_tanh_fwd: alignment/bias");
     WU_REQUIRE((long long)N * H * W < (1ll << 31), "conv1x1_tanh_fwd: N*H*W must stay below 2^31 (32-bit pixel arithmetic)");
-    const int grid = grid_cap((long long)N * H * W, 256 / LP, 256 * 16);
-    if (dtype == WU_BF16) hipLaunchKernelGGL(conv1x1_tanh_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, w, bias, out_nchw, N, H * W, Cin);
-    else hipLaunchKernelGGL(conv1x1_tanh_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, w, bias, out_nchw, N, H * W, Cin);
+    WU_REQUIRE((long long)H * W * ldx < (1ll << 31) && N <= 65535, "conv1x1_tanh_fwd: H*W*ldx must stay below 2^31, N below 65536");
+    // x = pixel groups of one image (two groups of 256/LP pixels per workgroup iteration), y = image; ~16 workgroups per CU in total
+    const int per_img = grid_cap((long long)H * W, 2 * (256 / LP), (256 * 16 + N - 1) / N);
+    const dim3 grid(per_img, N);
+#define C1F(T, L) hipLaunchKernelGGL((conv1x1_tanh_fwd_kernel<T, L>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, w, bias, out_nchw, H * W, Cin)
+    if (dtype == WU_BF16) { if (LP == 8) C1F(bf16_t, 8); else C1F(bf16_t, 0); }
+    else { if (LP == 16) C1F(float, 16); else C1F(float, 0); }
+#undef C1F
     WU_LAUNCH_CHECK("conv1x1_tanh_fwd");
     return 0;
 }
