@@ -131,6 +131,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import cunet
+    import ops
     from wu import _lib
     from wu.ddp import GradBucketReducer, ready_order
 
@@ -184,7 +185,7 @@ def main():
         else:
             opt.zero_grad(set_to_none=True)
         out = net(x, c)
-        loss = torch.mean(torch.abs(out - x))
+        loss = ops.l1_loss(out, x)                 # mean|G(x,c) - x| (reference ops.py:22-24)
         loss.backward()
         if reducer is not None:
             reducer.finalize()

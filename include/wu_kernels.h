@@ -205,6 +205,12 @@ int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int ldx, const f
 /* The keep-mask wu_adain_upcat_fwd draws for (seed, p): mask[n][c][h2][w2] (NCHW uint8), for tests. */
 int wu_dropout_mask(uint8_t* mask_nchw, int N, int H2, int W2, int C, float p_drop, uint64_t seed, void* stream);
 
+/* Mean absolute error between two fp32 tensors of n elements (reference ops.py:22-24 l1_loss = F.l1_loss): *loss = mean|a - b|
+ * and, when grad != NULL, grad[i] = sign(a[i] - b[i]) / n (the gradient wrt a for an upstream gradient of 1), in one pass.
+ * scratch: wu_l1_mean_scratch_floats() floats of per-workgroup partial sums, folded in index order (deterministic). */
+size_t wu_l1_mean_scratch_floats(void);
+int wu_l1_mean(const float* a, const float* b, float* grad, float* scratch, float* loss, long long n, void* stream);
+
 /* Discriminator head (disc.py:32): feat[n][c] = sum_{h,w} x[n,h,w,c]  (fp32), and its backward
  * dx[n,h,w,c] = dfeat[n][c]. */
 int wu_sumpool_fwd(const void* x, int ldx, float* feat, int N, int H, int W, int C, int dtype, void* stream);

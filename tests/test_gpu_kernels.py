@@ -461,3 +461,24 @@ def test_adain_upcat_bwd_marching_vs_gather(p):
             scale = max(1.0, b_.abs().max().item())
             assert (a_ - b_).abs().max().item() <= (1e-4 if p == "fp32" else 2e-2) * scale, k
     assert torch.equal(res[(1, False)][0], res[(1, True)][0])        # stored keep-bits == regenerated mask
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 24), (3, 5, 7), (1, 3, 64, 64)])
+def test_l1_loss_fused(shape):
+    """ops.l1_loss on fp32 device tensors (reference ops.py:22-24): value and both gradients against the torch op, including an
+    element count that is not a multiple of 4, exact zeros in a - b (sign 0) and a non-unit upstream gradient."""
+    import ops
+    a = _rand(shape, 71)
+    b = _rand(shape, 72)
+    b.view(-1)[::7] = a.view(-1)[::7]                    # exact ties: sign(0) = 0
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (F.l1_loss(ar, br) * 3.0).backward()
+    ag, bg = a.to(_dev()).requires_grad_(True), b.to(_dev()).requires_grad_(True)
+    loss = ops.l1_loss(ag, bg)
+    (loss * 3.0).backward()
+    assert abs(loss.item() - F.l1_loss(a, b).item()) <= 1e-6 * max(1.0, F.l1_loss(a, b).item())
+    # sign(a - b) * (3 / n): the scale may differ from torch's by one rounding (1/n * 3 vs 3/n)
+    assert torch.allclose(ag.grad.cpu(), ar.grad, rtol=1e-6, atol=0) and torch.allclose(bg.grad.cpu(), br.grad, rtol=1e-6, atol=0)
+    assert torch.equal(ag.grad.cpu() == 0, ar.grad == 0)
+    # run-to-run identical (fixed summation order)
+    assert ops.l1_loss(ag.detach(), bg.detach()).item() == ops.l1_loss(ag.detach(), bg.detach()).item()

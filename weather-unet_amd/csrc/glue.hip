@@ -858,6 +858,49 @@ inline uint32_t keep_thr(float p) {
     return (uint32_t)((1.0 - (double)p) * 65536.0 + 0.5);
 }
 
+
+// =================================================================================================
+// mean absolute error (ops.py:22-24) with its gradient in the same pass
+// =================================================================================================
+// loss = mean |a - b| over n fp32 elements; grad (optional) = sign(a - b) / n, i.e. d loss / d a.  Each workgroup leaves one
+// partial sum; l1_mean_fold_kernel adds them in index order (deterministic).  The autograd composition of sub / abs / mean and
+// their backward is nine launches and six passes over the data; this is two launches and one pass.
+constexpr int kL1MaxBlocks = 1024;
+__global__ __launch_bounds__(256) void l1_mean_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ grad,
+                                                              float* __restrict__ part, long long n4, long long n, float inv_n) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 u = ((const float4*)a)[i], v = ((const float4*)b)[i];
+        const float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
+        acc += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+        if (grad) {
+            // torch.sign semantics: 0 at 0
+            ((float4*)grad)[i] = make_float4(d0 > 0.f ? inv_n : (d0 < 0.f ? -inv_n : 0.f), d1 > 0.f ? inv_n : (d1 < 0.f ? -inv_n : 0.f),
+                                             d2 > 0.f ? inv_n : (d2 < 0.f ? -inv_n : 0.f), d3 > 0.f ? inv_n : (d3 < 0.f ? -inv_n : 0.f));
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {          // up to three tail elements
+        const long long i = 4 * n4 + threadIdx.x;
+        const float d = a[i] - b[i];
+        acc += fabsf(d);
+        if (grad) grad[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void l1_mean_fold_kernel(const float* __restrict__ part, int nblk, float inv_n, float* __restrict__ loss) {
+    // 64 lanes x fixed stride, then a fixed xor tree: the same summation order on every run
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 64) acc += part[i];
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if (threadIdx.x == 0) *loss = acc * inv_n;
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, ...)                         \
@@ -1010,6 +1053,22 @@ extern "C" int wu_dropout_mask(uint8_t* mask_nchw, int N, int H2, int W2, int C,
     const long long total = (long long)N * H2 * W2 * C;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, mask_nchw, N, H2, W2, C, keep_thr(p_drop), seed);
     WU_LAUNCH_CHECK("dropout_mask");
+    return 0;
+}
+
+extern "C" size_t wu_l1_mean_scratch_floats(void) { return (size_t)kL1MaxBlocks; }
+
+extern "C" int wu_l1_mean(const float* a, const float* b, float* grad, float* scratch, float* loss, long long n, void* stream) {
+    WU_REQUIRE(a && b && scratch && loss && n > 0, "l1_mean: bad args");
+    WU_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && (!grad || ((uintptr_t)grad % 16) == 0), "l1_mean: 16-byte alignment");
+    const long long n4 = n / 4;
+    long long g = (n4 + 256 * 8 - 1) / (256 * 8);          // ~8 float4 per thread
+    if (g > kL1MaxBlocks) g = kL1MaxBlocks;
+    if (g < 1) g = 1;
+    const float inv_n = (float)(1.0 / (double)n);
+    hipLaunchKernelGGL(l1_mean_partial_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a, b, grad, scratch, n4, n, inv_n);
+    hipLaunchKernelGGL(l1_mean_fold_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, (int)g, inv_n, loss);
+    WU_LAUNCH_CHECK("l1_mean");
     return 0;
 }
 

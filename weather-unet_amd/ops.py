@@ -30,8 +30,12 @@ def adv_loss(a, b):
 
 
 def l1_loss(a, b):
-    """ops.py:22-24: mean absolute error (logged as g_loss_l1, not part of g_loss)."""
+    """ops.py:22-24: mean absolute error (logged as g_loss_l1, not part of g_loss).  fp32 device tensors take the fused
+    one-pass kernel (loss and its gradient together); anything else is the stock torch op."""
     _same_size(a, b)
+    if a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.numel() > 0:
+        from wu.functional import l1_mean
+        return l1_mean(a, b)
     return F.l1_loss(a, b)
 
 

@@ -54,6 +54,8 @@ SIGNATURES = {
     "wu_adain_upcat_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, F, U64, P, P, I, I, P]),
     "wu_adain_upcat_bwd": (I, [P, I, P, I, P, P, P, I, P, P, P, P, I, I, I, I, F, U64, P, I, I, P]),
     "wu_dropout_mask": (I, [P, I, I, I, I, F, U64, P]),
+    "wu_l1_mean_scratch_floats": (SZ, []),
+    "wu_l1_mean": (I, [P, P, P, P, P, ctypes.c_longlong, P]),
     "wu_sumpool_fwd": (I, [P, I, P, I, I, I, I, I, P]),
     "wu_sumpool_bwd": (I, [P, P, I, I, I, I, I, I, P]),
     "wu_nhwc_to_nchw_f32": (I, [P, I, P, I, I, I, I, I, P]),

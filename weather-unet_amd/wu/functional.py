@@ -269,6 +269,27 @@ def conv1x1_tanh(x, weight, bias):
 # ----------------------------------------------------------------------------------------------
 # discriminator head: global sum pool        disc.py:32
 # ----------------------------------------------------------------------------------------------
+class L1MeanFn(Function):
+    """mean|a - b| (reference ops.py:22-24) with the gradient sign(a - b)/n produced by the forward's single pass."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        loss, grad = K.l1_mean(a, b, need)
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        g = ctx.grad * gout
+        return (g if ctx.needs_input_grad[0] else None), (-g if ctx.needs_input_grad[1] else None)
+
+
+def l1_mean(a, b):
+    """Fused mean absolute error for two same-shaped fp32 device tensors."""
+    return L1MeanFn.apply(a.contiguous(), b.contiguous())
+
+
 class SumPoolFn(Function):
     @staticmethod
     def forward(ctx, x):

@@ -206,6 +206,17 @@ def conv1x1_tanh_bwd(gout, out, x, w3c, dx, dw, db, x_gate_act=ACT_NONE, accumul
               n, h, w, cin, 1 if accumulate else 0, x_gate_act, dtype_code(x), stream_ptr())
 
 
+def l1_mean(a, b, want_grad):
+    """(mean|a - b| as a 0-dim fp32 tensor, sign(a - b) / n or None) for two contiguous fp32 tensors of the same shape."""
+    n = a.numel()
+    scratch = torch.empty(_lib.load().wu_l1_mean_scratch_floats(), dtype=torch.float32, device=a.device)
+    loss = torch.empty((), dtype=torch.float32, device=a.device)
+    grad = torch.empty_like(a) if want_grad else None
+    _lib.call("wu_l1_mean", a.data_ptr(), b.data_ptr(), grad.data_ptr() if want_grad else None, scratch.data_ptr(), loss.data_ptr(),
+              n, stream_ptr())
+    return loss, grad
+
+
 def pack_conv3x3(weight, code):
     """(w_fwd [9][Cout][Cin], w_dgrad [9][Cin][Cout]) in the compute dtype."""
     from .layout import torch_dtype
