@@ -342,7 +342,7 @@ extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, cons
     hipStream_t s = (hipStream_t)stream;
     const bool m = mask != nullptr;
     const int fam = stride == 2 ? WU_FAM_CONV_S2 : (m ? WU_FAM_CONV_DGRAD : WU_FAM_CONV_FWD);
-    if (g_wu_opt[WU_OPT_CONV_V2] && conv_v2_eligible(H, W, ldx, Cin, Cout, stride, dtype, m) && (egate == nullptr || act == WU_ACT_NONE)) {
+    if (g_wu_opt[WU_OPT_CONV_V2] && conv_v2_eligible(H, W, ldx, ldy, Cin, Cout, stride, dtype, m) && (egate == nullptr || (act == WU_ACT_NONE && bias == nullptr))) {
         wu_prof_pre(fam, s);
         const int rc = conv_v2_launch(x, ldx, w_packed, bias, y, ldy, egate, ldegate, egate_act, N, H, W, Cin, Cout, act, s);
         WU_REQUIRE(rc == 0, "conv3x3_fwd: grid too large");
@@ -378,7 +378,7 @@ extern "C" int wu_conv3x3_relu_pool_fwd(const void* x, int ldx, const void* w_pa
     const bool fused = g_wu_opt[WU_OPT_CONV_V2] && dtype == WU_BF16 && x && y && w_packed && N > 0 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 64 == 0 &&
                        ldx >= Cin && ldy >= Cout && (ldx * esz) % 16 == 0 && (ldy * esz) % 16 == 0 &&
                        ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 &&
-                       conv_v2_eligible(H, W, ldx, Cin, Cout, 1, dtype, false);
+                       conv_v2_eligible(H, W, ldx, ldy, Cin, Cout, 1, dtype, false);
     if (fused) {
         wu_prof_pre(WU_FAM_CONV_FWD, s);
         const int rc = conv_v2_launch(x, ldx, w_packed, bias, y, ldy, nullptr, 0, 0, N, H, W, Cin, Cout, WU_ACT_RELU, s, pool, ldpool);

@@ -73,7 +73,9 @@ __device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& 
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
 
-template <int NW>
+// GATED: the data-gradient form (gate tensor in the epilogue, no bias) -- a separate instance so that the gate prefetch registers
+// (32 / 64) and the bias registers (32) are never allocated together
+template <int NW, bool GATED>
 __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a) {
     using Q = KW<NW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -116,14 +118,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
     // halo: pixel p = i >> 2 = (hy, hx) relative to the halo origin (oh0-1, ow0-1), LDS 16-B slot sl = i & 3 holds channel
     // slot sl ^ swz(hx).  The descriptor base is shifted back by one row + one pixel so the offsets are non-negative.
     unsigned hoff[Q::NH];
-    int hpos[Q::NH];
 #pragma unroll
     for (int j = 0; j < Q::NH; ++j) {
         const int i = (NW * j + wave) * 64 + lane;
         const int p = i >> 2, sl = i & 3;
         const int hy = p / K::HALO_W, hx = p - hy * K::HALO_W;
         hoff[j] = p < K::HALO_PIX ? (unsigned)(((hy * a.W + hx) * a.ldx + (sl ^ ((hx >> 2) & 3)) * 8) * 2) : kWuOOB;
-        hpos[j] = (hy << 8) | hx;
     }
     // weights: row = i >> 2 = tap*64 + co, slot sl holds channel slot sl ^ swz(co): byte offset relative to the cout tile
     unsigned woff[Q::NWT];
@@ -153,7 +153,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         const int xmax = __builtin_amdgcn_readfirstlane(a.W - ow0);
 #pragma unroll
         for (int j = 0; j < Q::NH; ++j) {
-            const int hy = hpos[j] >> 8, hx = hpos[j] & 255;
+            // (hy, hx) recomputed per tile from the lane's slot index rather than kept in a register per piece
+            const int p_ = ((NW * j + wave) * 64 + lane) >> 2, hy = p_ / K::HALO_W, hx = p_ - hy * K::HALO_W;
             hv[j] = (hy >= ymin && hx >= xmin && hx <= xmax) ? hoff[j] : kWuOOB;
         }
     };
@@ -192,7 +193,23 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
     if (NW == 8 && a.prio_mode == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int nchunks = a.Cin / 32;
     int buf = 0;                                  // LDS buffer holding the chunk being computed
-    bool stores_in_flight = false;                // true after an epilogue whose NST store instructions all issued
+    bool stores_in_flight = false;                // true after a chunk 0 in which all NST deferred stores were issued
+    // Deferred output stores.  A tile's epilogue only PACKS its results (bias, activation, bf16, gate: registers `ov`); the NST
+    // 16-byte stores are issued one per K-step from inside the NEXT tile's first chunk, behind that chunk's DMA pieces, so the
+    // store traffic runs under matrix work instead of in front of it (stores were ~4000 of a Cin = 64 tile's ~19000 cycles;
+    // with the stores removed the forward convs ran 9 %, the data-gradient convs 16 % faster).  `ov` takes the place the bias /
+    // gate prefetch registers have in the last chunk, so the register peak does not move.
+    uint4 ov[Q::NST];
+    const bf16_t* ov_img = a.y;                   // (uniform) image of the pending tile in y
+    unsigned ov_off = 0;                          // this lane's byte offset of store 0 inside that image (< 2^31: host check)
+    unsigned ov_ok = 0;                           // bit k: store k of this lane is inside the image
+    bool ov_pending = false, ov_interior = false;
+    const unsigned ov_row = (unsigned)(a.W * a.ldy * 2);                 // bytes per output row
+    auto store_ov = [&](int k) __attribute__((always_inline)) {
+        // k = ((mp * 2 + ni) * 2 + gp) * 2 + r  ->  row 2 mp + r, channels + 32 ni + 16 gp
+        const int r = k & 1, gp = (k >> 1) & 1, ni = (k >> 2) & 1, mp = k >> 3;
+        if ((ov_ok >> k) & 1u) *(uint4*)((char*)ov_img + (ov_off + (unsigned)(2 * mp + r) * ov_row + (unsigned)(64 * ni + 32 * gp))) = ov[k];
+    };
     Tc cur = decode(t_begin), fetch = cur;
     set_fetch_tile(fetch);
 #pragma unroll
@@ -209,16 +226,18 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
-        // bias of this tile's 64 channels, in the transposed-accumulator layout (4 consecutive channels per register quad).
-        // Requested right AFTER chunk 0's wait (below), not here: a load issued between the previous epilogue's stores and
-        // that wait would be the youngest vector-memory op and make the counted vmcnt wait drain the stores.
+        // bias of this tile's 64 channels, in the transposed-accumulator layout (4 consecutive channels per register quad)
         float4 bvq[2][4];
         uint4 egv[Q::RPW][2][2];      // gate values (dgrad): prefetched in the last chunk
-        for (int c = 0; c < nchunks; ++c) {
+        // One K chunk.  Chunk 0 is a separate instance of this code (FIRST): only it issues the previous tile's deferred stores, and
+        // it is never the last chunk (Cin >= 64) -- so `ov` is dead before the loop over the later chunks, where the bias / gate
+        // registers come alive (inside one loop the allocator has to keep all three sets at once: 47 spilled registers).
+        auto do_chunk = [&](const int c, auto first_tag) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             const char* lds = smem + buf * K::BUF;
             const int nxt = buf ^ 1;
             // what to fetch while computing this chunk: the next chunk of this tile, or chunk 0 of the next tile
-            const bool last = c + 1 == nchunks;
+            const bool last = !FIRST && c + 1 == nchunks;
             const bool more = !last || tile + t_step < t_end;
             const int c1 = last ? 0 : (c + 1) * 32;
             // this wave's pieces of the current chunk must have landed.  Right after an interior tile's epilogue the 8
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
             WU_STAMP(t_wait);
             __syncthreads();     // ... and so have everyone else's; everyone is also done with the other buffer
             WU_STAMP(t_epi_b2);  // (diagnostic) chunk-top barrier time is folded into the 'barrier2' slot
-            if (c == 0) {
+            if (last && !GATED) {      // requested in the LAST chunk: lands under its MFMAs, and its registers are free for `ov` before
                 const int ct_ = cur.ct;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
@@ -241,7 +260,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
             if (last && more) { fetch = advance(fetch); set_fetch_tile(fetch); }
             // the gate values of this tile's outputs are requested at the start of its LAST chunk: they land under the MFMAs
             // instead of stalling every store of the epilogue (out-of-image pixels are clamped, their stores are skipped)
-            if (last && a.egate) {
+            if (last && GATED) {
                 const int ct_ = cur.ct, tx_ = cur.tx, ty_ = cur.ty, n_ = cur.n;
 #pragma unroll
                 for (int mi = 0; mi < Q::RPW; ++mi) {
@@ -280,6 +299,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                         issue_piece(2 * step, c1, nxt);
                         if (2 * step + 1 < Q::NP) issue_piece(2 * step + 1, c1, nxt);
                     }
+                    // the previous tile's outputs, one store per step once this chunk's DMA pieces are out (they stay the
+                    // youngest vector-memory ops: the next chunk-top wait is vmcnt(NST))
+                    static_assert(2 * 5 >= Q::NP || NW != 8, "deferred stores must follow the last DMA piece");
+                    if (FIRST && ov_pending && step >= 5 && step < 5 + Q::NST) store_ov(step - 5);
                     // pin the order: left alone, the scheduler sinks the fragment reads of the DMA-free steps (6..17) to just
                     // before their first use and waits lgkmcnt(0) in front of every MFMA
                     __builtin_amdgcn_sched_barrier(0);
@@ -319,16 +342,25 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                             issue_piece(2 * step, c1, nxt, kill);
                             if (2 * step + 1 < Q::NP) issue_piece(2 * step + 1, c1, nxt, kill);
                         }
+                        // the previous tile's 16 outputs: two stores behind the last MFMA of steps 10 .. 17 (after the DMA pieces)
+                        static_assert(2 * 10 >= Q::NP || NW != 4, "deferred stores must follow the last DMA piece");
+                        if (FIRST && m == NM - 1 && ov_pending && step >= 10 && 2 * (step - 10) + 1 < Q::NST) {
+                            store_ov(2 * (step - 10));
+                            store_ov(2 * (step - 10) + 1);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
             buf = nxt;
-            if (c == 0) WU_STAMP(t_comp); else WU_STAMP(t_comp_rest);
-        }
+            if (FIRST && ov_pending) { stores_in_flight = ov_interior; ov_pending = false; }
+            if (FIRST) WU_STAMP(t_comp); else WU_STAMP(t_comp_rest);
+        };
+        do_chunk(0, std::true_type{});
+        for (int c = 1; c < nchunks; ++c) do_chunk(c, std::false_type{});
 
         // ---- epilogue of this tile (its last chunk sat in buffer buf^1, now free; buffer `buf` is receiving the next
-        //      tile's chunk 0): bias + activation in fp32, [pixel][cout] image through LDS, 16-B coalesced stores ----
+        //      tile's chunk 0): bias + activation in fp32, packed to bf16 in registers (`ov`); the stores follow later ----
         const int n = cur.n;
         const int oh0 = cur.ty * K::TH, ow0 = cur.tx * K::TW, co0 = cur.ct * 64;
         // Direct epilogue, no LDS and no workgroup barrier: bias + activation in fp32, bf16 packing, then one
@@ -357,7 +389,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                             uint32_t o[2][2];
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
-                                const float4 bv = bvq[ni][g + h];
+                                const float4 bv = GATED ? make_float4(0.f, 0.f, 0.f, 0.f) : bvq[ni][g + h];
                                 const int r0 = 4 * (g + h);
                                 f32x2_t v0 = f32x2_t{acc[mi][ni][r0 + 0], acc[mi][ni][r0 + 1]} + f32x2_t{bv.x, bv.y};
                                 f32x2_t v1 = f32x2_t{acc[mi][ni][r0 + 2], acc[mi][ni][r0 + 3]} + f32x2_t{bv.z, bv.w};
@@ -383,9 +415,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                                     v = gate16<bf16_t>(v, yv, WU_ACT_LEAKY);
                                 }
                             }
-                            const int oh = ohe + r;
-                            if (oh < a.H && ow < a.W)
-                                *(uint4*)(a.y + (img_pix + (size_t)(oh * a.W + ow)) * a.ldy + co0 + 8 * lh + 32 * ni + 8 * g) = v;
+                            ov[((mp * 2 + ni) * 2 + (g >> 1)) * 2 + r] = v;       // stored from inside the next tile's first chunk
                             vr[r] = v;
                         }
                         if (POOL) {
@@ -408,21 +438,39 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         using A1 = std::integral_constant<int, WU_ACT_RELU>;
         using A2 = std::integral_constant<int, WU_ACT_LEAKY>;
         using NoPool = std::false_type;
-        if (a.egate) {                     // host guarantees act == NONE with a gate (conv_v2_eligible)
+        if constexpr (GATED) {             // host guarantees act == NONE and no bias with a gate (conv_v2_launch)
             if (a.egate_act == WU_ACT_RELU) epi_store(A0{}, A1{}, NoPool{});
-            else if (a.egate_act == WU_ACT_LEAKY) epi_store(A0{}, A2{}, NoPool{});
+            else epi_store(A0{}, A2{}, NoPool{});
+        } else {
+            if (a.act == WU_ACT_RELU) {
+                if (a.pool) epi_store(A1{}, A0{}, std::true_type{});      // host guarantees act == RELU with a pool output
+                else epi_store(A1{}, A0{}, NoPool{});
+            }
+            else if (a.act == WU_ACT_LEAKY) epi_store(A2{}, A0{}, NoPool{});
             else epi_store(A0{}, A0{}, NoPool{});
-        } else if (a.act == WU_ACT_RELU) {
-            if (a.pool) epi_store(A1{}, A0{}, std::true_type{});      // host guarantees act == RELU with a pool output
-            else epi_store(A1{}, A0{}, NoPool{});
         }
-        else if (a.act == WU_ACT_LEAKY) epi_store(A2{}, A0{}, NoPool{});
-        else epi_store(A0{}, A0{}, NoPool{});
-        // interior tile: every lane issued all NST stores (the counted vmcnt wait at the next chunk top relies on it); with the
-        // pool output the number of store instructions differs per wave half -> plain vmcnt(0) there
-        stores_in_flight = oh0 + K::TH <= a.H && ow0 + K::TW <= a.W && !a.pool;
+        // where the deferred stores go: lane base = pixel (oh0 + RPW wave, ow0 + l31), channel co0 + 8 lh; bit k of ov_ok = store k
+        // lies inside the image.  Interior tile: every lane will issue all NST stores (the counted vmcnt wait after the next
+        // tile's first chunk relies on it).
+        {
+            const int ohw = oh0 + Q::RPW * wave, ow = ow0 + l31;
+            ov_img = a.y + img_pix * a.ldy;
+            ov_off = (unsigned)(((ohw * a.W + ow) * a.ldy + co0 + 8 * lh) * 2);
+            unsigned rows = 0;
+#pragma unroll
+            for (int rr = 0; rr < Q::RPW; ++rr) rows |= (ohw + rr < a.H && ow < a.W) ? (1u << rr) : 0u;
+            ov_ok = 0;
+#pragma unroll
+            for (int k = 0; k < Q::NST; ++k) ov_ok |= ((rows >> (2 * (k >> 3) + (k & 1))) & 1u) << k;
+            ov_interior = oh0 + K::TH <= a.H && ow0 + K::TW <= a.W;
+            ov_pending = true;
+        }
         WU_STAMP(t_epi_s);
         cur = advance(cur);
+    }
+    if (ov_pending) {                // the last tile's outputs
+#pragma unroll
+        for (int k = 0; k < Q::NST; ++k) store_ov(k);
     }
     if (NW == 4) dma_wait_all();     // the killed pieces of the last chunk still write LDS: drain before the LDS is released
     if (a.dbg && lane == 0) {
@@ -435,10 +483,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
 
 }  // namespace
 
-bool conv_v2_eligible(int H, int W, int ldx, int Cin, int Cout, int stride, int dtype, bool masked) {
+bool conv_v2_eligible(int H, int W, int ldx, int ldy, int Cin, int Cout, int stride, int dtype, bool masked) {
     // 32-bit DMA byte offsets below kWuOOB: the weight pack and one (row + pixel padded) image
-    return dtype == WU_BF16 && stride == 1 && !masked && W > 16 && W <= 4096 && Cin % 32 == 0 && Cout % 64 == 0 &&
-           (size_t)9 * Cout * Cin * 2 < (1ull << 31) && ((size_t)H * W + W + 2) * (size_t)ldx * 2 < (1ull << 31);
+    return dtype == WU_BF16 && stride == 1 && !masked && W > 16 && W <= 4096 && Cin % 32 == 0 && Cin >= 64 && Cout % 64 == 0 &&
+           (size_t)9 * Cout * Cin * 2 < (1ull << 31) && ((size_t)H * W + W + 2) * (size_t)ldx * 2 < (1ull << 31) &&
+           ((size_t)H * W + W + 2) * (size_t)ldy * 2 < (1ull << 31);
 }
 
 int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
@@ -460,14 +509,23 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     const long long grid = (ntiles < cus || !g_wu_opt[WU_OPT_CONV_PERSISTENT]) ? ntiles : cus;
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     // one wave per SIMD with 8 accumulators pays off once a tile has >= 8 chunks (fewer LDS reads per MFMA, no intra-SIMD
     // skew); with few chunks per tile its un-overlapped epilogue costs more than that.  option 0: 1 = auto, 2 = always 4, 3 = always 8
     const int mode = g_wu_opt[WU_OPT_CONV_V2];
-    if (mode == 2 || (mode == 1 && Cin >= 256)) hipLaunchKernelGGL(conv3x3_mfma_v2_kernel<4>, dim3((int)grid), dim3(256), 2 * K::BUF, s, a);
-    else hipLaunchKernelGGL(conv3x3_mfma_v2_kernel<8>, dim3((int)grid), dim3(512), 2 * K::BUF, s, a);
+    const bool gated = egate != nullptr && egate_act != WU_ACT_NONE;
+    if (!gated) a.egate = nullptr;
+    if (mode == 2 || (mode == 1 && Cin >= 256)) {
+        if (gated) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<4, true>), dim3((int)grid), dim3(256), 2 * K::BUF, s, a);
+        else hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<4, false>), dim3((int)grid), dim3(256), 2 * K::BUF, s, a);
+    } else {
+        if (gated) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<8, true>), dim3((int)grid), dim3(512), 2 * K::BUF, s, a);
+        else hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<8, false>), dim3((int)grid), dim3(512), 2 * K::BUF, s, a);
+    }
     return 0;
 }

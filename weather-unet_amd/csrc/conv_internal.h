@@ -2,7 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-bool conv_v2_eligible(int H, int W, int ldx, int Cin, int Cout, int stride, int dtype, bool masked);
+// ldy: pixel stride of the output (32-bit byte offsets inside one output image, like ldx for the input)
+bool conv_v2_eligible(int H, int W, int ldx, int ldy, int Cin, int Cout, int stride, int dtype, bool masked);
 // pool != NULL (act must be ReLU, no gate): the epilogue also writes the 2x2 max-pool of y
 int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
                    const void* egate, int ldegate, int egate_act, int N, int H, int W, int Cin, int Cout, int act, hipStream_t s,
