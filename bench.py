@@ -137,6 +137,10 @@ def main():
 
     for kv in a.opt:
         k, v = kv.split("=")
+        if k == "gate_bits":                   # host-side A/B switch: ReLU gates as bits (default) or as tensors
+            from wu import unet_graph as _UG
+            _UG.GATE_BITS = bool(int(v))
+            continue
         _lib.call("wu_set_option", int(k), int(v))
     torch.manual_seed(0)                       # same random-init weights on every rank
     net = cunet.Conditional_UNet(5, precision=a.precision).to(dev)

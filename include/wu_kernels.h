@@ -90,6 +90,22 @@ int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, const float* bi
                    const void* mask, int ldmask, int mask_act,
                    const void* egate, int ldegate, int egate_act, int dtype, void* stream);
 
+/* "Gate bits": the ReLU gate of an activation tensor y (N,H,W,C; C % 64 == 0) as one bit per element instead of the tensor,
+ *     uint32 bits[N*H*W][C/64][2];   bit (8k + i) of bits[p][ct][hf]  =  y[p][64 ct + 16 k + 8 hf + i] > 0   (k < 4, i < 8)
+ * -- the 32 channels one lane of the conv epilogue holds, so a gated epilogue reads one dword per lane and row where the gate
+ * tensor costs four 16-byte loads (the gated data-gradient convs of the 64-channel 256x256 layers are HBM-bound: 805 -> 554 MB).
+ * wu_conv3x3_fwd_bits is wu_conv3x3_fwd (stride 1, bf16) with either
+ *   gate_bits_out != NULL: act must be WU_ACT_RELU; the bits of the output are written next to y (forward of a block's first conv), or
+ *   egate_bits   != NULL: act = NONE, bias = NULL; the output is multiplied by the gate the bits encode (data-gradient pass of the
+ *                          block's second conv; egate_bits has the OUTPUT geometry, Cout channels).
+ * Only the LDS-DMA kernel has this epilogue: wu_conv3x3_gate_bits_supported(...) != 0 must hold for the shape (else use the
+ * gate-tensor form of wu_conv3x3_fwd).  wu_gate_bits_bytes: size of a bits buffer. */
+int wu_conv3x3_gate_bits_supported(int H, int W, int ldx, int ldy, int Cin, int Cout, int dtype);
+size_t wu_gate_bits_bytes(int N, int H, int W, int C);
+int wu_conv3x3_fwd_bits(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                        void* gate_bits_out, const void* egate_bits, int N, int H, int W, int Cin, int Cout,
+                        int act, int dtype, void* stream);
+
 /* y = ReLU(conv3x3(x) + bias) AND pool = max_pool2d(y, 2) (floor: [N][H/2][W/2][Cout], pixel stride ldpool) in one call
  * (cunet.py:45-46, 49-50, 53-54).  On the bf16 LDS-DMA path the conv epilogue writes the pooled tensor itself; otherwise the
  * conv is followed by wu_maxpool2_fwd.  Same argument rules as wu_conv3x3_fwd (stride 1); H and W even. */
@@ -129,6 +145,11 @@ int wu_act_gate(const void* g, int ldg, const void* y, int ldy, void* out, int l
 int wu_conv3x3_c3_fwd(const float* x_nchw, const float* w_oihw, const float* bias, const float* inv_sigma,
                       void* y, int ldy, int out_nchw, int N, int H, int W, int Cout, int stride, int act,
                       int dtype, void* stream);
+/* wu_conv3x3_c3_fwd with NHWC output, Cout = 64, ReLU, that also writes the gate bits of its output (see "gate bits" above;
+ * the matrix-core form only: wu_conv3x3_c3_gate_bits_supported(...) != 0). */
+int wu_conv3x3_c3_gate_bits_supported(int N, int H, int W, int Cout, int stride, const float* bias, int dtype);
+int wu_conv3x3_c3_fwd_bits(const float* x_nchw, const float* w_oihw, const float* bias, const float* inv_sigma,
+                           void* y, int ldy, void* gate_bits_out, int N, int H, int W, int Cout, int stride, int dtype, void* stream);
 /* its weight/bias gradient (the image needs no data gradient in the generator); dy NHWC or NCHW fp32 */
 int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy, int dy_nchw, const void* y, int ldy_,
                         int act, float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes,

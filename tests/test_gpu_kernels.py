@@ -482,3 +482,77 @@ def test_l1_loss_fused(shape):
     assert torch.equal(ag.grad.cpu() == 0, ar.grad == 0)
     # run-to-run identical (fixed summation order)
     assert ops.l1_loss(ag.detach(), bg.detach()).item() == ops.l1_loss(ag.detach(), bg.detach()).item()
+
+
+def _decode_gate_bits(bits, n, c, h, w):
+    """uint32 [N*H*W][C/64][2] -> bool (N,C,H,W): bit 8k+i of word (p, ct, hf) is channel 64ct + 16k + 8hf + i (wu_kernels.h)."""
+    b = bits.cpu().numpy().view("uint32").reshape(n, h, w, c // 64, 2)
+    out = torch.zeros((n, c, h, w), dtype=torch.bool)
+    for ct in range(c // 64):
+        for hf in range(2):
+            word = b[:, :, :, ct, hf]
+            for k in range(4):
+                for i in range(8):
+                    out[:, 64 * ct + 16 * k + 8 * hf + i] = torch.from_numpy(((word >> (8 * k + i)) & 1).astype("bool"))
+    return out
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 16, 32), (1, 64, 128, 24, 40), (2, 256, 128, 20, 40), (1, 128, 64, 33, 35)])
+def test_conv3x3_gate_bits(shape):
+    """ReLU gates carried as bits: the forward writes exactly (y > 0) next to an unchanged y; the data-gradient pass gated by
+    the bits equals the one gated by the tensor bit for bit (both conv3x3_mfma_v2 instances, both wave counts, ragged tiles)."""
+    from wu import kernels as K
+    from wu.layout import empty_nhwc, precision_code
+    n, cin, cout, h, w = shape
+    p = "bf16"
+    x = _nhwc(_round(_rand((n, cin, h, w), 81), p), p)
+    wt = _round(_rand((cout, cin, 3, 3), 82, -0.1, 0.1), p).to(_dev())
+    b = _rand((cout,), 83).to(_dev())
+    wf, wd = K.pack_conv3x3(wt, precision_code(p))
+    y0 = empty_nhwc(n, cout, h, w, x.dtype, x.device)
+    y1 = empty_nhwc(n, cout, h, w, x.dtype, x.device)
+    assert K.gate_bits_supported(x, y0)
+    K.conv3x3(x, wf, b, y0, 1, 1)
+    bits = K.gate_bits_alloc(y1)
+    bits.fill_(-1)
+    K.conv3x3_bits(x, wf, b, y1, 1, gate_bits_out=bits)
+    assert torch.equal(y0, y1)
+    assert torch.equal(_decode_gate_bits(bits, n, cout, h, w), (y0.float() > 0).cpu())
+    # data gradient of this conv's OUTPUT-side neighbour: dx = conv(gy, w_dgrad) gated by ReLU'(x_prev) with x_prev := some tensor
+    gy = _nhwc(_round(_rand((n, cout, h, w), 84), p), p)
+    prev = _nhwc(torch.relu(_round(_rand((n, cin, h, w), 85), p)), p)          # the "mid" activation whose gate is applied (Cin channels)
+    pbits = K.gate_bits_alloc(prev)
+    # bits of `prev` through the same writer: a forward conv that reproduces prev is not available, so build them on the host
+    pb = torch.zeros((n, h, w, cin // 64, 2), dtype=torch.int64)
+    pos = (prev.float() > 0).cpu()
+    for ct in range(cin // 64):
+        for hf in range(2):
+            for k in range(4):
+                for i in range(8):
+                    pb[:, :, :, ct, hf] |= pos[:, 64 * ct + 16 * k + 8 * hf + i].long() << (8 * k + i)
+    pb = torch.where(pb >= 2 ** 31, pb - 2 ** 32, pb).to(torch.int32)
+    pbits.copy_(pb.reshape(-1).to(_dev()))
+    d0 = empty_nhwc(n, cin, h, w, x.dtype, x.device)
+    d1 = empty_nhwc(n, cin, h, w, x.dtype, x.device)
+    K.conv3x3(gy, wd, None, d0, 1, 0, egate=prev, egate_act=1)
+    K.conv3x3_bits(gy, wd, None, d1, 0, egate_bits=pbits)
+    assert torch.equal(d0, d1)
+
+
+def test_conv3x3_c3_gate_bits():
+    from wu import kernels as K
+    from wu.layout import empty_nhwc, precision_code
+    n, h, w = 2, 24, 40
+    x = _rand((n, 3, h, w), 91).to(_dev())
+    wt = _rand((64, 3, 3, 3), 92, -0.3, 0.3).to(_dev())
+    b = _rand((64,), 93).to(_dev())
+    code = precision_code("bf16")
+    y0 = empty_nhwc(n, 64, h, w, torch.bfloat16, x.device)
+    y1 = empty_nhwc(n, 64, h, w, torch.bfloat16, x.device)
+    assert K.conv3x3_c3_bits_supported(x, wt, b, 1, code)
+    K.conv3x3_c3(x, wt, b, y0, 1, 1, False, code)
+    bits = K.gate_bits_alloc(y1)
+    bits.fill_(-1)
+    K.conv3x3_c3_bits(x, wt, b, y1, bits, 1, code)
+    assert torch.equal(y0, y1)
+    assert torch.equal(_decode_gate_bits(bits, n, 64, h, w), (y0.float() > 0).cpu())

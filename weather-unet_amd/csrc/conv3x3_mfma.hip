@@ -366,6 +366,36 @@ extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, cons
     return 0;
 }
 
+// ReLU gates carried as bits between a forward conv and the data-gradient conv of the same block (wu_kernels.h, "gate bits").
+// Only the LDS-DMA kernel (conv3x3_mfma_v2) has this epilogue: callers ask wu_conv3x3_gate_bits_supported first.
+extern "C" int wu_conv3x3_gate_bits_supported(int H, int W, int ldx, int ldy, int Cin, int Cout, int dtype) {
+    return (g_wu_opt[WU_OPT_CONV_V2] && conv_v2_eligible(H, W, ldx, ldy, Cin, Cout, 1, dtype, false)) ? 1 : 0;
+}
+
+extern "C" size_t wu_gate_bits_bytes(int N, int H, int W, int C) { return (size_t)N * H * W * (size_t)(C / 64) * 2 * sizeof(unsigned); }
+
+extern "C" int wu_conv3x3_fwd_bits(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                                   void* gate_bits_out, const void* egate_bits, int N, int H, int W, int Cin, int Cout,
+                                   int act, int dtype, void* stream) {
+    WU_REQUIRE(N > 0 && H > 0 && W > 0 && x && y && w_packed, "conv3x3_fwd_bits: bad args");
+    WU_REQUIRE(wu_conv3x3_gate_bits_supported(H, W, ldx, ldy, Cin, Cout, dtype), "conv3x3_fwd_bits: shape/dtype outside the LDS-DMA conv (ask wu_conv3x3_gate_bits_supported)");
+    WU_REQUIRE(ldx >= Cin && ldy >= Cout && (ldx * 2) % 16 == 0 && (ldy * 2) % 16 == 0, "conv3x3_fwd_bits: bad ld (%d,%d)", ldx, ldy);
+    WU_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)w_packed % 16) == 0, "conv3x3_fwd_bits: pointers must be 16-B aligned");
+    WU_REQUIRE(!(gate_bits_out && egate_bits), "conv3x3_fwd_bits: a pass either writes gate bits (forward) or reads them (data gradient)");
+    WU_REQUIRE((unsigned long long)N * H * W * (unsigned long long)(Cout / 64) * 2 < (1ull << 32), "conv3x3_fwd_bits: gate-word index must fit 32 bits");
+    if (gate_bits_out) WU_REQUIRE(act == WU_ACT_RELU && ((uintptr_t)gate_bits_out % 4) == 0, "conv3x3_fwd_bits: gate bits are written with act == RELU");
+    if (egate_bits) WU_REQUIRE(act == WU_ACT_NONE && bias == nullptr && ((uintptr_t)egate_bits % 4) == 0, "conv3x3_fwd_bits: a gated pass has no bias / activation");
+    hipStream_t s = (hipStream_t)stream;
+    wu_prof_pre(WU_FAM_CONV_FWD, s);
+    const int rc = conv_v2_launch(x, ldx, w_packed, bias, y, ldy, nullptr, 0, 0, N, H, W, Cin, Cout, act, s, nullptr, 0, gate_bits_out, egate_bits);
+    WU_REQUIRE(rc == 0, "conv3x3_fwd_bits: grid too large");
+    // a gate word is 1/16 of the bf16 tensor it stands for
+    wu_prof_post(WU_FAM_CONV_FWD, s, 2.0 * N * H * W * (double)Cout * 9.0 * Cin,
+                 ((double)N * H * W * (Cin + Cout) + 9.0 * Cin * Cout) * 2 + ((gate_bits_out || egate_bits) ? (double)N * H * W * Cout / 8.0 : 0.0));
+    WU_LAUNCH_CHECK("conv3x3_mfma_v2 (gate bits)");
+    return 0;
+}
+
 // conv3x3 + bias + ReLU with its 2x2 max-pool from the same epilogue (cunet.py:45-46, 49-50, 53-54: every encoder block's
 // second conv feeds both the skip tensor y and max_pool2d(y)).  On the LDS-DMA path the pooled tensor is written by the conv
 // kernel itself (the stand-alone pool kernel re-reads all of y: 470 MB per B=32 step); otherwise conv, then the pool kernel.

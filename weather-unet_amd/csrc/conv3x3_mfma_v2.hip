@@ -42,6 +42,11 @@ template <int NW_> struct KW {
 struct V2Args {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; const bf16_t* egate;
     bf16_t* pool;                // optional: 2x2 max-pool of y (ReLU outputs), written from the same epilogue
+    // ReLU gate as BITS (include/wu_kernels.h, "gate bits"): uint32 [pixel][Cout/64][2]; bit 8k + i of word (pixel, ct, hf) is
+    // y[pixel][64 ct + 16 k + 8 hf + i] > 0 -- exactly the 32 channels lane (pixel, hf) holds in the epilogue, so a gate is one
+    // dword per lane and row instead of four 16-byte loads
+    unsigned* gbits;             // optional output (forward, act == RELU)
+    const unsigned* egbits;      // optional input (data gradient): replaces egate / egate_act = RELU
     int ldx, ldy, ldegate, egate_act, ldpool;
     int N, H, W, Cin, Cout, act;
     int tiles_x, tiles_y, cout_tiles, ntiles, prio_mode, strided;
@@ -68,14 +73,32 @@ __device__ __forceinline__ uint32_t max_u16x2(uint32_t a, uint32_t b) {
     const u16x2_t m = __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b));
     return __builtin_bit_cast(uint32_t, m);
 }
+// bit e = (element e of eight NON-NEGATIVE bf16 != 0).  v_pk_min_u16 with 1 turns a pair into 0/1 per half (inline asm: the compiler
+// rewrites the equivalent C into a compare + select per element, ~30 instructions per group); three v_lshl_or gather the four
+// dwords (low halves at bits 0,2,4,6, high halves at 16,18,20,22) and one shift-or folds the high halves onto bits 1,3,5,7.
+__device__ __forceinline__ uint32_t nonzero_byte(const uint4& v) {
+    uint32_t t0, t1, t2, t3;
+    const uint32_t one = 0x00010001u;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t0) : "v"(v.x), "v"(one));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t1) : "v"(v.y), "v"(one));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t2) : "v"(v.z), "v"(one));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t3) : "v"(v.w), "v"(one));
+    const uint32_t xx = ((t3 << 6) | t2 << 4) | ((t1 << 2) | t0);
+    return (xx | (xx >> 15)) & 0xffu;
+}
+// AND mask for a packed bf16 pair from two adjacent gate bits: bit b -> low half, bit b + 1 -> high half (v_bfe_i32 x 2 + merge)
+__device__ __forceinline__ uint32_t gate_mask2(int bits, int b) {
+    const uint32_t lo = (uint32_t)((bits << (31 - b)) >> 31), hi = (uint32_t)((bits << (30 - b)) >> 31);
+    return (lo & 0xffffu) | (hi << 16);
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
 
-// GATED: the data-gradient form (gate tensor in the epilogue, no bias) -- a separate instance so that the gate prefetch registers
-// (32 / 64) and the bias registers (32) are never allocated together
-template <int NW, bool GATED>
+// GATED: the data-gradient form (a gate in the epilogue, no bias): 1 = gate tensor, 2 = gate bits -- separate instances so that
+// the gate-tensor prefetch registers (32 / 64), the bias registers (32) and neither of them are allocated as each case needs
+template <int NW, int GATED>
 __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a) {
     using Q = KW<NW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -194,6 +217,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
     const int nchunks = a.Cin / 32;
     int buf = 0;                                  // LDS buffer holding the chunk being computed
     bool stores_in_flight = false;                // true after a chunk 0 in which all NST deferred stores were issued
+    bool bits_in_flight = false;                  // ... followed by the RPW gate-word stores
     // Deferred output stores.  A tile's epilogue only PACKS its results (bias, activation, bf16, gate: registers `ov`); the NST
     // 16-byte stores are issued one per K-step from inside the NEXT tile's first chunk, behind that chunk's DMA pieces, so the
     // store traffic runs under matrix work instead of in front of it (stores were ~4000 of a Cin = 64 tile's ~19000 cycles;
@@ -204,6 +228,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
     unsigned ov_off = 0;                          // this lane's byte offset of store 0 inside that image (< 2^31: host check)
     unsigned ov_ok = 0;                           // bit k: store k of this lane is inside the image
     bool ov_pending = false, ov_interior = false;
+    unsigned ovb[Q::RPW];                         // the pending tile's gate words (forward with gate bits), stored after `ov`
+    unsigned ovb_off = 0;                         // this lane's dword index of row 0's gate word
+    bool ovb_pending = false;
+    auto store_ovb = [&](int mi) __attribute__((always_inline)) {
+        if ((ov_ok >> (8 * (mi >> 1) + (mi & 1))) & 1u) a.gbits[ovb_off + (unsigned)mi * (unsigned)(a.W * 2 * a.cout_tiles)] = ovb[mi];
+    };
     const unsigned ov_row = (unsigned)(a.W * a.ldy * 2);                 // bytes per output row
     auto store_ov = [&](int k) __attribute__((always_inline)) {
         // k = ((mp * 2 + ni) * 2 + gp) * 2 + r  ->  row 2 mp + r, channels + 32 ni + 16 gp
@@ -229,6 +259,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         // bias of this tile's 64 channels, in the transposed-accumulator layout (4 consecutive channels per register quad)
         float4 bvq[2][4];
         uint4 egv[Q::RPW][2][2];      // gate values (dgrad): prefetched in the last chunk
+        unsigned egb[Q::RPW];         // gate bits (dgrad): one dword per row
         // One K chunk.  Chunk 0 is a separate instance of this code (FIRST): only it issues the previous tile's deferred stores, and
         // it is never the last chunk (Cin >= 64) -- so `ov` is dead before the loop over the later chunks, where the bias / gate
         // registers come alive (inside one loop the allocator has to keep all three sets at once: 47 spilled registers).
@@ -243,7 +274,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
             // this wave's pieces of the current chunk must have landed.  Right after an interior tile's epilogue the 8
             // output stores are the YOUNGEST vector-memory ops and every DMA piece is older: vmcnt(8) retires the DMA
             // without draining the stores to HBM (vmcnt counts loads, stores and LDS-DMA together, in issue order).
-            if (stores_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q::NST) : "memory");
+            if (stores_in_flight && bits_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q::NST + Q::RPW) : "memory");
+            else if (stores_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q::NST) : "memory");
             else dma_wait_all();
             stores_in_flight = false;
             WU_STAMP(t_wait);
@@ -260,7 +292,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
             if (last && more) { fetch = advance(fetch); set_fetch_tile(fetch); }
             // the gate values of this tile's outputs are requested at the start of its LAST chunk: they land under the MFMAs
             // instead of stalling every store of the epilogue (out-of-image pixels are clamped, their stores are skipped)
-            if (last && GATED) {
+            if (last && GATED == 1) {
                 const int ct_ = cur.ct, tx_ = cur.tx, ty_ = cur.ty, n_ = cur.n;
 #pragma unroll
                 for (int mi = 0; mi < Q::RPW; ++mi) {
@@ -270,6 +302,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                         for (int gp = 0; gp < 2; ++gp) egv[mi][ni][gp] = *(const uint4*)(ep + 32 * ni + 16 * gp);
+                }
+            }
+            if (last && GATED == 2) {
+                const int ct_ = cur.ct, tx_ = cur.tx, ty_ = cur.ty, n_ = cur.n;
+#pragma unroll
+                for (int mi = 0; mi < Q::RPW; ++mi) {
+                    const int oh = min(ty_ * K::TH + Q::RPW * wave + mi, a.H - 1), ow = min(tx_ * K::TW + l31, a.W - 1);
+                    egb[mi] = a.egbits[(((size_t)n_ * a.H + oh) * a.W + ow) * (2 * a.cout_tiles) + 2 * ct_ + lh];
                 }
             }
             // 18 steps (tap, ks), software-pipelined by hand: the fragments of step s+1 are requested BEFORE the four
@@ -303,6 +343,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                     // youngest vector-memory ops: the next chunk-top wait is vmcnt(NST))
                     static_assert(2 * 5 >= Q::NP || NW != 8, "deferred stores must follow the last DMA piece");
                     if (FIRST && ov_pending && step >= 5 && step < 5 + Q::NST) store_ov(step - 5);
+                    if (GATED == 0 && FIRST && ovb_pending && step >= 5 + Q::NST && step < 5 + Q::NST + Q::RPW) store_ovb(step - 5 - Q::NST);
                     // pin the order: left alone, the scheduler sinks the fragment reads of the DMA-free steps (6..17) to just
                     // before their first use and waits lgkmcnt(0) in front of every MFMA
                     __builtin_amdgcn_sched_barrier(0);
@@ -348,12 +389,13 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                             store_ov(2 * (step - 10));
                             store_ov(2 * (step - 10) + 1);
                         }
+                        if (GATED == 0 && FIRST && m == NM - 1 && ovb_pending && step >= 18 - Q::RPW) store_ovb(step - (18 - Q::RPW));
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
             buf = nxt;
-            if (FIRST && ov_pending) { stores_in_flight = ov_interior; ov_pending = false; }
+            if (FIRST && ov_pending) { stores_in_flight = ov_interior; bits_in_flight = ovb_pending; ov_pending = false; ovb_pending = false; }
             if (FIRST) WU_STAMP(t_comp); else WU_STAMP(t_comp_rest);
         };
         do_chunk(0, std::true_type{});
@@ -375,6 +417,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         auto epi_store = [&](auto act_tag, auto eg_tag, auto pool_tag) __attribute__((always_inline)) {
             constexpr int ACT = decltype(act_tag)::value, EG = decltype(eg_tag)::value;
             constexpr bool POOL = decltype(pool_tag)::value;       // only with ACT == RELU (non-negative outputs)
+            unsigned gb[Q::RPW];
+#pragma unroll
+            for (int i = 0; i < Q::RPW; ++i) gb[i] = 0u;
 #pragma unroll
             for (int mp = 0; mp < Q::RPW / 2; ++mp) {                // the wave's rows in vertical pairs (even, odd)
                 const int ohe = oh0 + Q::RPW * wave + 2 * mp, ow = ow0 + l31;
@@ -406,7 +451,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                             const auto s0 = __builtin_amdgcn_permlane32_swap(o[0][0], o[1][0], false, false);
                             const auto s1 = __builtin_amdgcn_permlane32_swap(o[0][1], o[1][1], false, false);
                             uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                            if (EG != WU_ACT_NONE) {
+                            if (GATED == 2) {
+                                // byte k of the row's gate word: element e of this 16-byte group passes iff bit e is set
+                                const int by = (int)(egb[mi] >> (8 * (2 * ni + (g >> 1))));
+                                v.x &= gate_mask2(by, 0);
+                                v.y &= gate_mask2(by, 2);
+                                v.z &= gate_mask2(by, 4);
+                                v.w &= gate_mask2(by, 6);
+                            } else if (EG != WU_ACT_NONE) {
                                 const uint4 yv = egv[mi][ni][g >> 1];
                                 if (EG == WU_ACT_RELU) {
                                     v.x = relu_gate_bf16x2(v.x, yv.x); v.y = relu_gate_bf16x2(v.y, yv.y);
@@ -417,6 +469,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                             }
                             ov[((mp * 2 + ni) * 2 + (g >> 1)) * 2 + r] = v;       // stored from inside the next tile's first chunk
                             vr[r] = v;
+                            if (GATED == 0 && ACT == WU_ACT_RELU && a.gbits)
+                                gb[2 * mp + r] |= nonzero_byte(v) << (8 * (2 * ni + (g >> 1)));
                         }
                         if (POOL) {
                             // 2x2 max-pool (cunet.py:46,50,54) of the ReLU outputs: non-negative bf16 order like unsigned integers,
@@ -433,12 +487,20 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                         }
                     }
             }
+            if (GATED == 0 && ACT == WU_ACT_RELU && a.gbits) {       // parked like `ov`: issued from the next tile's first chunk
+#pragma unroll
+                for (int mi = 0; mi < Q::RPW; ++mi) ovb[mi] = gb[mi];
+                ovb_off = (unsigned)((((size_t)n * a.H + oh0 + Q::RPW * wave) * a.W + ow0 + l31) * (2 * a.cout_tiles) + 2 * cur.ct + lh);
+                ovb_pending = true;
+            }
         };
         using A0 = std::integral_constant<int, WU_ACT_NONE>;
         using A1 = std::integral_constant<int, WU_ACT_RELU>;
         using A2 = std::integral_constant<int, WU_ACT_LEAKY>;
         using NoPool = std::false_type;
-        if constexpr (GATED) {             // host guarantees act == NONE and no bias with a gate (conv_v2_launch)
+        if constexpr (GATED == 2) {        // ReLU gate from bits
+            epi_store(A0{}, A0{}, NoPool{});
+        } else if constexpr (GATED == 1) { // host guarantees act == NONE and no bias with a gate (conv_v2_launch)
             if (a.egate_act == WU_ACT_RELU) epi_store(A0{}, A1{}, NoPool{});
             else epi_store(A0{}, A2{}, NoPool{});
         } else {
@@ -471,6 +533,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
     if (ov_pending) {                // the last tile's outputs
 #pragma unroll
         for (int k = 0; k < Q::NST; ++k) store_ov(k);
+        if (GATED == 0 && ovb_pending) {
+#pragma unroll
+            for (int mi = 0; mi < Q::RPW; ++mi) store_ovb(mi);
+        }
     }
     if (NW == 4) dma_wait_all();     // the killed pieces of the last chunk still write LDS: drain before the LDS is released
     if (a.dbg && lane == 0) {
@@ -492,7 +558,7 @@ bool conv_v2_eligible(int H, int W, int ldx, int ldy, int Cin, int Cout, int str
 
 int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
                    const void* egate, int ldegate, int egate_act, int N, int H, int W, int Cin, int Cout, int act, hipStream_t s,
-                   void* pool, int ldpool) {
+                   void* pool, int ldpool, void* gate_bits_out, const void* egate_bits) {
     V2Args a;
     a.pool = (bf16_t*)pool; a.ldpool = ldpool;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.egate = (const bf16_t*)egate;
@@ -509,23 +575,22 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     const long long grid = (ntiles < cus || !g_wu_opt[WU_OPT_CONV_PERSISTENT]) ? ntiles : cus;
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define WU_V2_ATTR(NW_, G_) (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<NW_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        WU_V2_ATTR(8, 0); WU_V2_ATTR(4, 0); WU_V2_ATTR(8, 1); WU_V2_ATTR(4, 1); WU_V2_ATTR(8, 2); WU_V2_ATTR(4, 2);
+#undef WU_V2_ATTR
         attr_set = true;
     }
     // one wave per SIMD with 8 accumulators pays off once a tile has >= 8 chunks (fewer LDS reads per MFMA, no intra-SIMD
     // skew); with few chunks per tile its un-overlapped epilogue costs more than that.  option 0: 1 = auto, 2 = always 4, 3 = always 8
     const int mode = g_wu_opt[WU_OPT_CONV_V2];
-    const bool gated = egate != nullptr && egate_act != WU_ACT_NONE;
-    if (!gated) a.egate = nullptr;
-    if (mode == 2 || (mode == 1 && Cin >= 256)) {
-        if (gated) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<4, true>), dim3((int)grid), dim3(256), 2 * K::BUF, s, a);
-        else hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<4, false>), dim3((int)grid), dim3(256), 2 * K::BUF, s, a);
-    } else {
-        if (gated) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<8, true>), dim3((int)grid), dim3(512), 2 * K::BUF, s, a);
-        else hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<8, false>), dim3((int)grid), dim3(512), 2 * K::BUF, s, a);
-    }
+    const int gated = egate_bits ? 2 : ((egate != nullptr && egate_act != WU_ACT_NONE) ? 1 : 0);
+    if (gated != 1) a.egate = nullptr;
+    a.egbits = (const unsigned*)egate_bits;
+    a.gbits = (gated == 0 && act == WU_ACT_RELU) ? (unsigned*)gate_bits_out : nullptr;
+    const bool nw4 = mode == 2 || (mode == 1 && Cin >= 256);
+#define WU_V2_GO(NW_, G_) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<NW_, G_>), dim3((int)grid), dim3(NW_ * 64), 2 * K::BUF, s, a)
+    if (nw4) { if (gated == 2) WU_V2_GO(4, 2); else if (gated == 1) WU_V2_GO(4, 1); else WU_V2_GO(4, 0); }
+    else { if (gated == 2) WU_V2_GO(8, 2); else if (gated == 1) WU_V2_GO(8, 1); else WU_V2_GO(8, 0); }
+#undef WU_V2_GO
     return 0;
 }

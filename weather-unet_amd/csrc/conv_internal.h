@@ -7,4 +7,6 @@ bool conv_v2_eligible(int H, int W, int ldx, int ldy, int Cin, int Cout, int str
 // pool != NULL (act must be ReLU, no gate): the epilogue also writes the 2x2 max-pool of y
 int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
                    const void* egate, int ldegate, int egate_act, int N, int H, int W, int Cin, int Cout, int act, hipStream_t s,
-                   void* pool = nullptr, int ldpool = 0);
+                   void* pool = nullptr, int ldpool = 0,
+                   // ReLU gate as bits (wu_conv3x3_fwd_bits): written by a forward with act == RELU / read by a data-gradient pass
+                   void* gate_bits_out = nullptr, const void* egate_bits = nullptr);

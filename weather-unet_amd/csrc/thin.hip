@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(const float* __rest
 template <int STRIDE, int ACT, bool FULL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv3x3_c3_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, const float* __restrict__ inv_sigma,
-                                                                  bf16_t* __restrict__ y, int ldy, int N, int H, int W) {
+                                                                  bf16_t* __restrict__ y, int ldy, int N, int H, int W,
+                                                                  unsigned char* __restrict__ gbits) {
     __shared__ __attribute__((aligned(16))) char tile[4 * 32 * 144];
     __shared__ __attribute__((aligned(16))) float bias_s[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -182,10 +183,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             // FULL (total % 32 == 0): unconditional stores.  Behind a branch the compiler cannot count them and waits vmcnt(0)
             // -- their write acknowledgements -- before it touches the prefetched patch at the top of the next iteration.
             if (FULL || p2 < total) *(uint4*)(y + (size_t)p2 * ldy + sl * 8) = v4;
+            if (ACT == WU_ACT_RELU && gbits && (FULL || p2 < total)) {
+                // gate bits (wu_kernels.h): this lane's 8 channels 8 sl .. 8 sl + 7 are byte sl >> 1 of word (pixel, 0, sl & 1)
+                uint32_t t0, t1, t2, t3;
+                const uint32_t one = 0x00010001u;          // v_pk_min_u16 with 1: 0/1 per non-negative bf16 half (see conv3x3_mfma_v2.hip)
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(t0) : "v"(v4.x), "v"(one));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(t1) : "v"(v4.y), "v"(one));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(t2) : "v"(v4.z), "v"(one));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(t3) : "v"(v4.w), "v"(one));
+                const uint32_t xx = t0 | (t1 << 2) | (t2 << 4) | (t3 << 6);
+                gbits[(size_t)p2 * 8 + (sl & 1) * 4 + (sl >> 1)] = (unsigned char)((xx | (xx >> 15)) & 0xffu);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         // the next block's patch has landed (the registers named here are exactly the asm loads' destinations)
-        if (FULL) asm volatile("s_waitcnt vmcnt(4)" : WU_V16(vn) : : "memory");
+        // (with gate bits every store is followed by a byte store: eight younger operations instead of four)
+        if (FULL && ACT == WU_ACT_RELU && gbits) asm volatile("s_waitcnt vmcnt(8)" : WU_V16(vn) : : "memory");
+        else if (FULL) asm volatile("s_waitcnt vmcnt(4)" : WU_V16(vn) : : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : WU_V16(vn) : : "memory");
     }
 #undef WU_V16
@@ -923,9 +937,16 @@ inline int grid_cap(long long work_items, int per_block, int cap) {
 
 }  // namespace
 
-extern "C" int wu_conv3x3_c3_fwd(const float* x_nchw, const float* w_oihw, const float* bias, const float* inv_sigma,
-                                 void* y, int ldy, int out_nchw, int N, int H, int W, int Cout, int stride, int act,
-                                 int dtype, void* stream) {
+// the matrix-core form of the 3 -> 64 forward applies (only it can write gate bits)
+static bool c3_fwd_mfma_ok(int N, int H, int W, int Cout, int stride, const float* bias, int dtype) {
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    return dtype == WU_BF16 && Cout == 64 && g_wu_opt[WU_OPT_C3_ROWS] == 0 && (!bias || ((uintptr_t)bias % 16) == 0) &&
+           (long long)N * Ho * Wo < (1ll << 31) - 64 && (long long)N * 3 * H * W < (1ll << 28);
+}
+
+static int c3_fwd_impl(const float* x_nchw, const float* w_oihw, const float* bias, const float* inv_sigma,
+                       void* y, int ldy, int out_nchw, int N, int H, int W, int Cout, int stride, int act,
+                       int dtype, void* stream, void* gate_bits_out) {
     WU_REQUIRE(stride == 1 || stride == 2, "conv3x3_c3_fwd: stride");
     WU_REQUIRE((Cout == 64 && !out_nchw) || (Cout == 3 && out_nchw && stride == 1), "conv3x3_c3_fwd: supported (Cout,layout): (64,NHWC) or (3,NCHW s1); got Cout=%d", Cout);
     const int esz = dtype == WU_BF16 ? 2 : 4;
@@ -940,13 +961,13 @@ extern "C" int wu_conv3x3_c3_fwd(const float* x_nchw, const float* w_oihw, const
     const int grid_l = grid_cap((long long)N * Ho * Wo, 256, 256 * 8);
     // fp32 path: the LDS-broadcast one-thread-per-pixel kernel (239 us at B=32 256x256 in bf16 storage; the scalar-weight /
     // transposed-store variant conv3x3_c3_fwd_rows_kernel measured 326 us and is kept selectable for A/B work)
-#define C3_MFMA_F(ST, A, F) hipLaunchKernelGGL((conv3x3_c3_fwd_mfma_kernel<ST, A, F>), dim3(grid_m), dim3(256), 0, s, x_nchw, w_oihw, bias, inv_sigma, (bf16_t*)y, ldy, N, H, W)
+#define C3_MFMA_F(ST, A, F) hipLaunchKernelGGL((conv3x3_c3_fwd_mfma_kernel<ST, A, F>), dim3(grid_m), dim3(256), 0, s, x_nchw, w_oihw, bias, inv_sigma, (bf16_t*)y, ldy, N, H, W, (unsigned char*)gate_bits_out)
 #define C3_MFMA_A(ST, A) do { if (((long long)N * Ho * Wo) % 32 == 0) C3_MFMA_F(ST, A, true); else C3_MFMA_F(ST, A, false); } while (0)
 #define C3_MFMA(ST) do { if (act == WU_ACT_RELU) C3_MFMA_A(ST, WU_ACT_RELU); else if (act == WU_ACT_LEAKY) C3_MFMA_A(ST, WU_ACT_LEAKY); else C3_MFMA_A(ST, WU_ACT_NONE); } while (0)
     const int grid_m = grid_cap((long long)N * Ho * Wo, 128, 256 * 16);
     // option 5: 0 = bf16 on the matrix cores (default), 1 = scalar-weight rows kernel, 2 = one-thread-per-pixel VALU kernel
     if (out_nchw) C3_LAUNCH(float, 3, 1, true);
-    else if (dtype == WU_BF16 && g_wu_opt[WU_OPT_C3_ROWS] == 0 && (!bias || ((uintptr_t)bias % 16) == 0) && (long long)N * Ho * Wo < (1ll << 31) - 64 && (long long)N * 3 * H * W < (1ll << 28)) { if (stride == 1) C3_MFMA(1); else C3_MFMA(2); }
+    else if (c3_fwd_mfma_ok(N, H, W, Cout, stride, bias, dtype)) { if (stride == 1) C3_MFMA(1); else C3_MFMA(2); }
     else if (g_wu_opt[WU_OPT_C3_ROWS] == 1) {
         if (dtype == WU_BF16) { if (stride == 1) C3_LANES(bf16_t, 1); else C3_LANES(bf16_t, 2); }
         else { if (stride == 1) C3_LANES(float, 1); else C3_LANES(float, 2); }
@@ -961,6 +982,22 @@ extern "C" int wu_conv3x3_c3_fwd(const float* x_nchw, const float* w_oihw, const
 #undef C3_LAUNCH
     WU_LAUNCH_CHECK("conv3x3_c3_fwd");
     return 0;
+}
+
+extern "C" int wu_conv3x3_c3_fwd(const float* x_nchw, const float* w_oihw, const float* bias, const float* inv_sigma,
+                                 void* y, int ldy, int out_nchw, int N, int H, int W, int Cout, int stride, int act,
+                                 int dtype, void* stream) {
+    return c3_fwd_impl(x_nchw, w_oihw, bias, inv_sigma, y, ldy, out_nchw, N, H, W, Cout, stride, act, dtype, stream, nullptr);
+}
+
+// wu_conv3x3_c3_fwd (NHWC output, ReLU) that also writes the gate bits of its output (wu_kernels.h, "gate bits")
+extern "C" int wu_conv3x3_c3_gate_bits_supported(int N, int H, int W, int Cout, int stride, const float* bias, int dtype) {
+    return c3_fwd_mfma_ok(N, H, W, Cout, stride, bias, dtype) ? 1 : 0;
+}
+extern "C" int wu_conv3x3_c3_fwd_bits(const float* x_nchw, const float* w_oihw, const float* bias, const float* inv_sigma,
+                                      void* y, int ldy, void* gate_bits_out, int N, int H, int W, int Cout, int stride, int dtype, void* stream) {
+    WU_REQUIRE(gate_bits_out && c3_fwd_mfma_ok(N, H, W, Cout, stride, bias, dtype), "conv3x3_c3_fwd_bits: outside the matrix-core path (ask wu_conv3x3_c3_gate_bits_supported)");
+    return c3_fwd_impl(x_nchw, w_oihw, bias, inv_sigma, y, ldy, 0, N, H, W, Cout, stride, WU_ACT_RELU, dtype, stream, gate_bits_out);
 }
 
 extern "C" size_t wu_thin_workspace_bytes(void) { return (size_t)kThinMaxBlocks * kC3Slab * sizeof(float); }

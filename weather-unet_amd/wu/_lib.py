@@ -34,6 +34,9 @@ SIGNATURES = {
     "wu_spectral_norm_bwd": (I, [P, P, P, P, P, P, I, I, P, P]),
     "wu_pack_conv3x3": (I, [P, P, P, I, I, P, I, P]),
     "wu_conv3x3_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P, I, I, P, I, I, I, P]),
+    "wu_conv3x3_gate_bits_supported": (I, [I, I, I, I, I, I, I]),
+    "wu_gate_bits_bytes": (SZ, [I, I, I, I]),
+    "wu_conv3x3_fwd_bits": (I, [P, I, P, P, P, I, P, P, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_relu_pool_fwd": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_wgrad_workspace": (SZ, [I, I, I, I, I, I, I]),
     "wu_conv3x3_wgrad": (I, [P, I, P, I, P, I, I, P, P, P, SZ, I, I, I, I, I, I, I, I, P]),
@@ -41,6 +44,8 @@ SIGNATURES = {
     "wu_conv3x3_s2_dgrad": (I, [P, I, P, I, I, P, P, I, P, SZ, P, I, I, I, I, I, I, I, I, P]),
     "wu_act_gate": (I, [P, I, P, I, P, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_c3_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "wu_conv3x3_c3_gate_bits_supported": (I, [I, I, I, I, I, P, I]),
+    "wu_conv3x3_c3_fwd_bits": (I, [P, P, P, P, P, I, P, I, I, I, I, I, I, P]),
     "wu_conv3x3_c3_wgrad": (I, [P, P, I, I, P, I, I, P, P, P, SZ, I, I, I, I, I, I, I, P]),
     "wu_thin_workspace_bytes": (SZ, []),
     "wu_conv3x3_c3_dgrad": (I, [P, I, I, P, I, I, P, P, P, I, I, I, I, I, I, I, P]),

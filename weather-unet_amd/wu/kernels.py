@@ -43,6 +43,27 @@ def conv3x3(x, w_packed, bias, y, stride=1, act=ACT_NONE, mask=None, mask_act=AC
     return y
 
 
+def gate_bits_supported(x, y):
+    """The LDS-DMA conv (the only one with the gate-bits epilogue) takes x -> y (both NHWC views)."""
+    n, cin, h, w = x.shape
+    return bool(_lib.load().wu_conv3x3_gate_bits_supported(h, w, nhwc_ld(x), nhwc_ld(y), cin, y.shape[1], dtype_code(x)))
+
+
+def gate_bits_alloc(y):
+    """A bits buffer for activation tensor y (wu_kernels.h, "gate bits": uint32 [N*H*W][C/64][2])."""
+    n, c, h, w = y.shape
+    return torch.empty(_lib.load().wu_gate_bits_bytes(n, h, w, c) // 4, dtype=torch.int32, device=y.device)
+
+
+def conv3x3_bits(x, w_packed, bias, y, act=ACT_NONE, gate_bits_out=None, egate_bits=None):
+    """wu_conv3x3_fwd_bits: the stride-1 bf16 conv that writes (forward, ReLU) or reads (data gradient) the ReLU gate as bits."""
+    n, cin, h, w = x.shape
+    _lib.call("wu_conv3x3_fwd_bits", x.data_ptr(), nhwc_ld(x), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+              y.data_ptr(), nhwc_ld(y), gate_bits_out.data_ptr() if gate_bits_out is not None else None,
+              egate_bits.data_ptr() if egate_bits is not None else None, n, h, w, cin, y.shape[1], act, dtype_code(x), stream_ptr())
+    return y
+
+
 def conv3x3_relu_pool(x, w_packed, bias, y, pool):
     """y = ReLU(conv3x3(x) + bias), pool = max_pool2d(y, 2) -- wu_conv3x3_relu_pool_fwd (fused epilogue on the bf16 path)."""
     n, cin, h, w = x.shape
@@ -92,6 +113,19 @@ def conv3x3_c3(x_nchw, weight, bias, y, stride, act, out_nchw, code):
     cout = weight.shape[0]
     _lib.call("wu_conv3x3_c3_fwd", x_nchw.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, None,
               y.data_ptr(), 0 if out_nchw else nhwc_ld(y), 1 if out_nchw else 0, n, h, w, cout, stride, act, code, stream_ptr())
+    return y
+
+
+def conv3x3_c3_bits_supported(x_nchw, weight, bias, stride, code):
+    n, _, h, w = x_nchw.shape
+    return bool(_lib.load().wu_conv3x3_c3_gate_bits_supported(n, h, w, weight.shape[0], stride, bias.data_ptr() if bias is not None else None, code))
+
+
+def conv3x3_c3_bits(x_nchw, weight, bias, y, gate_bits_out, stride, code):
+    """The 3 -> 64 ReLU conv that also writes the gate bits of its output (wu_conv3x3_c3_fwd_bits)."""
+    n, _, h, w = x_nchw.shape
+    _lib.call("wu_conv3x3_c3_fwd_bits", x_nchw.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, None,
+              y.data_ptr(), nhwc_ld(y), gate_bits_out.data_ptr(), n, h, w, weight.shape[0], stride, code, stream_ptr())
     return y
 
 

@@ -21,6 +21,8 @@ RELU = K.ACT_RELU
 # Weight-gradient kernels run on a second HIP stream: nothing in the backward chain consumes dW, so each one overlaps the
 # data-gradient kernel that follows it and the tails / ramps of the persistent one-workgroup-per-CU launches fill each other.
 SIDE_STREAM_WGRAD = True
+# ReLU gates between a block's two convs travel as bits (1/16 of the tensor) where the LDS-DMA conv runs (A/B switch)
+GATE_BITS = True
 _SIDE = {}
 SIDE_STREAM_LOG = []     # one entry per probe: which candidate won and the median timings (diagnostic)
 
@@ -160,14 +162,32 @@ class UNetFn(Function):
         cat3 = _new(n, 768, h // 4, w // 4, dt, dev)
         conv1, conv2, conv3 = cat1[:, 128:], cat2[:, 256:], cat3[:, 512:]
 
+        # The ReLU gate of every block's first conv output ("mid") is needed once more, by the data-gradient pass of the block's
+        # second conv: where the LDS-DMA conv runs, the forward leaves that gate as BITS (1/16 of the tensor) and the backward's
+        # epilogue reads one dword per lane and row instead of the tensor (wu_kernels.h, "gate bits").
+        gbits = {}
+
+        def mid_conv(name, xin, out):
+            """First conv of block `name`: conv + bias + ReLU, with gate bits when wanted and supported."""
+            if GATE_BITS and want_bits and K.gate_bits_supported(xin, out):
+                gbits[name] = K.gate_bits_alloc(out)
+                return K.conv3x3_bits(xin, pk[name + ".0"][0], wb[name][1], out, RELU, gate_bits_out=gbits[name])
+            return K.conv3x3(xin, pk[name + ".0"][0], wb[name][1], out, 1, RELU)
+
         # ---- encoder (cunet.py:45-54) ----
-        a1 = K.conv3x3_c3(x, wb["dconv_down1"][0].detach().contiguous(), wb["dconv_down1"][1], _new(n, 64, h, w, dt, dev), 1, RELU, False, code)
+        w_first = wb["dconv_down1"][0].detach().contiguous()
+        a1 = _new(n, 64, h, w, dt, dev)
+        if GATE_BITS and want_bits and K.conv3x3_c3_bits_supported(x, w_first, wb["dconv_down1"][1], 1, code) and K.gate_bits_supported(a1, a1):
+            gbits["dconv_down1"] = K.gate_bits_alloc(a1)
+            K.conv3x3_c3_bits(x, w_first, wb["dconv_down1"][1], a1, gbits["dconv_down1"], 1, code)
+        else:
+            K.conv3x3_c3(x, w_first, wb["dconv_down1"][1], a1, 1, RELU, False, code)
         p1 = K.conv3x3_relu_pool(a1, pk["dconv_down1.2"][0], wb["dconv_down1"][3], conv1, _new(n, 64, h // 2, w // 2, dt, dev))[1]
-        a2 = K.conv3x3(p1, pk["dconv_down2.0"][0], wb["dconv_down2"][1], _new(n, 128, h // 2, w // 2, dt, dev), 1, RELU)
+        a2 = mid_conv("dconv_down2", p1, _new(n, 128, h // 2, w // 2, dt, dev))
         p2 = K.conv3x3_relu_pool(a2, pk["dconv_down2.2"][0], wb["dconv_down2"][3], conv2, _new(n, 128, h // 4, w // 4, dt, dev))[1]
-        a3 = K.conv3x3(p2, pk["dconv_down3.0"][0], wb["dconv_down3"][1], _new(n, 256, h // 4, w // 4, dt, dev), 1, RELU)
+        a3 = mid_conv("dconv_down3", p2, _new(n, 256, h // 4, w // 4, dt, dev))
         p3 = K.conv3x3_relu_pool(a3, pk["dconv_down3.2"][0], wb["dconv_down3"][3], conv3, _new(n, 256, h // 8, w // 8, dt, dev))[1]
-        a4 = K.conv3x3(p3, pk["dconv_down4.0"][0], wb["dconv_down4"][1], _new(n, 512, h // 8, w // 8, dt, dev), 1, RELU)
+        a4 = mid_conv("dconv_down4", p3, _new(n, 512, h // 8, w // 8, dt, dev))
         b4 = K.conv3x3(a4, pk["dconv_down4.2"][0], wb["dconv_down4"][3], _new(n, 512, h // 8, w // 8, dt, dev), 1, RELU)
 
         # ---- decoder (cunet.py:59-78): adain -> upsample -> dropout -> cat fused, then r_double_conv ----
@@ -175,15 +195,15 @@ class UNetFn(Function):
         ym = [t.detach().float().contiguous() for t in (ym3, ym2, ym1)]
         st3 = K.adain_stats(b4, eps)
         mb3 = K.adain_upcat(b4, st3, ys[0], ym[0], cat3, p_drop, seeds[0], want_bits, seed_dev, inj[0])
-        u3a = K.conv3x3(cat3, pk["dconv_up3.0"][0], wb["dconv_up3"][1], _new(n, 256, h // 4, w // 4, dt, dev), 1, RELU)
+        u3a = mid_conv("dconv_up3", cat3, _new(n, 256, h // 4, w // 4, dt, dev))
         u3b = K.conv3x3(u3a, pk["dconv_up3.2"][0], wb["dconv_up3"][3], _new(n, 256, h // 4, w // 4, dt, dev), 1, RELU)
         st2 = K.adain_stats(u3b, eps)
         mb2 = K.adain_upcat(u3b, st2, ys[1], ym[1], cat2, p_drop, seeds[1], want_bits, seed_dev, inj[1])
-        u2a = K.conv3x3(cat2, pk["dconv_up2.0"][0], wb["dconv_up2"][1], _new(n, 128, h // 2, w // 2, dt, dev), 1, RELU)
+        u2a = mid_conv("dconv_up2", cat2, _new(n, 128, h // 2, w // 2, dt, dev))
         u2b = K.conv3x3(u2a, pk["dconv_up2.2"][0], wb["dconv_up2"][3], _new(n, 128, h // 2, w // 2, dt, dev), 1, RELU)
         st1 = K.adain_stats(u2b, eps)
         mb1 = K.adain_upcat(u2b, st1, ys[2], ym[2], cat1, p_drop, seeds[2], want_bits, seed_dev, inj[2])
-        u1a = K.conv3x3(cat1, pk["dconv_up1.0"][0], wb["dconv_up1"][1], _new(n, 64, h, w, dt, dev), 1, RELU)
+        u1a = mid_conv("dconv_up1", cat1, _new(n, 64, h, w, dt, dev))
         u1b = K.conv3x3(u1a, pk["dconv_up1.2"][0], wb["dconv_up1"][3], _new(n, 64, h, w, dt, dev), 1, RELU)
 
         # ---- head (cunet.py:80-82) ----
@@ -195,6 +215,7 @@ class UNetFn(Function):
                                   st3, st2, st1, ys[0], ys[1], ys[2], w3c, wb["dconv_down1"][0].detach())
             ctx.pk_dgrad = {k: v[1] for k, v in pk.items()}
             ctx.mbits = (mb3, mb2, mb1)
+            ctx.gbits = gbits
             ctx.meta = (code, p_drop, seeds, [tuple(p.shape) for p in P])
             # gradient sink (wu.ddp.GradBucketReducer.attach): weight gradients are accumulated straight into the parameters'
             # bucket-view .grad and announced layer by layer, so bucket all-reduces overlap the rest of this backward
@@ -209,6 +230,7 @@ class UNetFn(Function):
         code, p_drop, seeds, shapes = ctx.meta
         wd = ctx.pk_dgrad
         mb3, mb2, mb1 = ctx.mbits
+        gbits = ctx.gbits
         dev, dt = x.device, u1b.dtype
         n, _, h, w = x.shape
         f32 = dict(dtype=torch.float32, device=dev)
@@ -229,7 +251,11 @@ class UNetFn(Function):
         def block_bwd(name, xin, mid, g_out_gated, need_dx=True):
             """r_double_conv backward given the PRE-GATED gradient of its output; returns dL/d(xin) (ungated)."""
             wgrad(name, 2, mid, g_out_gated)
-            g_mid = K.conv3x3(g_out_gated, wd[name + ".2"], None, _new(*mid.shape, dt, dev), egate=mid, egate_act=RELU)
+            g_mid = _new(*mid.shape, dt, dev)
+            if name in gbits and K.gate_bits_supported(g_out_gated, g_mid):
+                K.conv3x3_bits(g_out_gated, wd[name + ".2"], None, g_mid, egate_bits=gbits[name])
+            else:
+                K.conv3x3(g_out_gated, wd[name + ".2"], None, g_mid, egate=mid, egate_act=RELU)
             if name == "dconv_down1":
                 # the first conv's weight gradient is the LAST kernel of the backward chain and nothing consumes it: it joins the
                 # other weight gradients on the side stream (which has slack) instead of extending the main stream's tail
