@@ -8,6 +8,7 @@ def main():
     from wu.layout import empty_nhwc
     dev = torch.device('cuda:0'); B = 32
     NWAVES = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    BITS = len(sys.argv) > 3 and sys.argv[3] == 'bits'        # forward with gate-bit output
     if len(sys.argv) > 2: _lib.call('wu_set_option', 6, int(sys.argv[2]))
     _lib.call('wu_set_option', 0, 3 if NWAVES == 8 else 2)
     dbg = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
@@ -16,11 +17,13 @@ def main():
         w = ((torch.rand((co, ci, 3, 3), device=dev) * 2 - 1) * 0.05)
         wf, wd = K.pack_conv3x3(w, 1); bias = torch.zeros(co, device=dev)
         y = empty_nhwc(B, co, s, s, torch.bfloat16, dev)
-        for _ in range(3): K.conv3x3(x, wf, bias, y, 1, 1)
+        gb = K.gate_bits_alloc(y)
+        run = (lambda: K.conv3x3_bits(x, wf, bias, y, 1, gate_bits_out=gb)) if BITS else (lambda: K.conv3x3(x, wf, bias, y, 1, 1))
+        for _ in range(3): run()
         torch.cuda.synchronize()
         _lib.call('wu_set_debug_buffer', dbg.data_ptr()); dbg.zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); K.conv3x3(x, wf, bias, y, 1, 1); e1.record(); torch.cuda.synchronize()
+        e0.record(); run(); e1.record(); torch.cuda.synchronize()
         _lib.call('wu_set_debug_buffer', None)
         d = dbg.view(256, 8, 8).double().cpu()[:, :NWAVES]
         raw7 = dbg.view(256, 8, 8)[:, :NWAVES, 7].cpu()

@@ -96,7 +96,8 @@ __device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& 
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
 
-// GATED: the data-gradient form (a gate in the epilogue, no bias): 1 = gate tensor, 2 = gate bits -- separate instances so that
+// GATED: 0 = forward; 1 / 2 = the data-gradient form (a gate in the epilogue, no bias) with the gate as a tensor / as bits;
+// 3 = forward (ReLU) that also writes the gate bits of its output -- separate instances so that
 // the gate-tensor prefetch registers (32 / 64), the bias registers (32) and neither of them are allocated as each case needs
 template <int NW, int GATED>
 __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a) {
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
             WU_STAMP(t_wait);
             __syncthreads();     // ... and so have everyone else's; everyone is also done with the other buffer
             WU_STAMP(t_epi_b2);  // (diagnostic) chunk-top barrier time is folded into the 'barrier2' slot
-            if (last && !GATED) {      // requested in the LAST chunk: lands under its MFMAs, and its registers are free for `ov` before
+            if (last && (GATED == 0 || GATED == 3)) {      // requested in the LAST chunk: lands under its MFMAs, and its registers are free for `ov` before
                 const int ct_ = cur.ct;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                     // youngest vector-memory ops: the next chunk-top wait is vmcnt(NST))
                     static_assert(2 * 5 >= Q::NP || NW != 8, "deferred stores must follow the last DMA piece");
                     if (FIRST && ov_pending && step >= 5 && step < 5 + Q::NST) store_ov(step - 5);
-                    if (GATED == 0 && FIRST && ovb_pending && step >= 5 + Q::NST && step < 5 + Q::NST + Q::RPW) store_ovb(step - 5 - Q::NST);
+                    if (GATED == 3 && FIRST && ovb_pending && step >= 5 + Q::NST && step < 5 + Q::NST + Q::RPW) store_ovb(step - 5 - Q::NST);
                     // pin the order: left alone, the scheduler sinks the fragment reads of the DMA-free steps (6..17) to just
                     // before their first use and waits lgkmcnt(0) in front of every MFMA
                     __builtin_amdgcn_sched_barrier(0);
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                             store_ov(2 * (step - 10));
                             store_ov(2 * (step - 10) + 1);
                         }
-                        if (GATED == 0 && FIRST && m == NM - 1 && ovb_pending && step >= 18 - Q::RPW) store_ovb(step - (18 - Q::RPW));
+                        if (GATED == 3 && FIRST && m == NM - 1 && ovb_pending && step >= 18 - Q::RPW) store_ovb(step - (18 - Q::RPW));
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                             uint32_t o[2][2];
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
-                                const float4 bv = GATED ? make_float4(0.f, 0.f, 0.f, 0.f) : bvq[ni][g + h];
+                                const float4 bv = (GATED == 1 || GATED == 2) ? make_float4(0.f, 0.f, 0.f, 0.f) : bvq[ni][g + h];
                                 const int r0 = 4 * (g + h);
                                 f32x2_t v0 = f32x2_t{acc[mi][ni][r0 + 0], acc[mi][ni][r0 + 1]} + f32x2_t{bv.x, bv.y};
                                 f32x2_t v1 = f32x2_t{acc[mi][ni][r0 + 2], acc[mi][ni][r0 + 3]} + f32x2_t{bv.z, bv.w};
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                             }
                             ov[((mp * 2 + ni) * 2 + (g >> 1)) * 2 + r] = v;       // stored from inside the next tile's first chunk
                             vr[r] = v;
-                            if (GATED == 0 && ACT == WU_ACT_RELU && a.gbits)
+                            if (GATED == 3 && ACT == WU_ACT_RELU)
                                 gb[2 * mp + r] |= nonzero_byte(v) << (8 * (2 * ni + (g >> 1)));
                         }
                         if (POOL) {
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                         }
                     }
             }
-            if (GATED == 0 && ACT == WU_ACT_RELU && a.gbits) {       // parked like `ov`: issued from the next tile's first chunk
+            if (GATED == 3 && ACT == WU_ACT_RELU) {       // parked like `ov`: issued from the next tile's first chunk
 #pragma unroll
                 for (int mi = 0; mi < Q::RPW; ++mi) ovb[mi] = gb[mi];
                 ovb_off = (unsigned)((((size_t)n * a.H + oh0 + Q::RPW * wave) * a.W + ow0 + l31) * (2 * a.cout_tiles) + 2 * cur.ct + lh);
@@ -498,7 +499,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         using A1 = std::integral_constant<int, WU_ACT_RELU>;
         using A2 = std::integral_constant<int, WU_ACT_LEAKY>;
         using NoPool = std::false_type;
-        if constexpr (GATED == 2) {        // ReLU gate from bits
+        if constexpr (GATED == 3) {        // forward + gate bits: ReLU, no pool (conv_v2_launch)
+            epi_store(A1{}, A0{}, NoPool{});
+        } else if constexpr (GATED == 2) { // ReLU gate from bits
             epi_store(A0{}, A0{}, NoPool{});
         } else if constexpr (GATED == 1) { // host guarantees act == NONE and no bias with a gate (conv_v2_launch)
             if (a.egate_act == WU_ACT_RELU) epi_store(A0{}, A1{}, NoPool{});
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
     if (ov_pending) {                // the last tile's outputs
 #pragma unroll
         for (int k = 0; k < Q::NST; ++k) store_ov(k);
-        if (GATED == 0 && ovb_pending) {
+        if (GATED == 3 && ovb_pending) {
 #pragma unroll
             for (int mi = 0; mi < Q::RPW; ++mi) store_ovb(mi);
         }
@@ -576,21 +579,22 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     static thread_local bool attr_set = false;
     if (!attr_set) {
 #define WU_V2_ATTR(NW_, G_) (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<NW_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-        WU_V2_ATTR(8, 0); WU_V2_ATTR(4, 0); WU_V2_ATTR(8, 1); WU_V2_ATTR(4, 1); WU_V2_ATTR(8, 2); WU_V2_ATTR(4, 2);
+        WU_V2_ATTR(8, 0); WU_V2_ATTR(4, 0); WU_V2_ATTR(8, 1); WU_V2_ATTR(4, 1); WU_V2_ATTR(8, 2); WU_V2_ATTR(4, 2); WU_V2_ATTR(8, 3); WU_V2_ATTR(4, 3);
 #undef WU_V2_ATTR
         attr_set = true;
     }
     // one wave per SIMD with 8 accumulators pays off once a tile has >= 8 chunks (fewer LDS reads per MFMA, no intra-SIMD
     // skew); with few chunks per tile its un-overlapped epilogue costs more than that.  option 0: 1 = auto, 2 = always 4, 3 = always 8
     const int mode = g_wu_opt[WU_OPT_CONV_V2];
-    const int gated = egate_bits ? 2 : ((egate != nullptr && egate_act != WU_ACT_NONE) ? 1 : 0);
+    int gated = egate_bits ? 2 : ((egate != nullptr && egate_act != WU_ACT_NONE) ? 1 : 0);
     if (gated != 1) a.egate = nullptr;
     a.egbits = (const unsigned*)egate_bits;
-    a.gbits = (gated == 0 && act == WU_ACT_RELU) ? (unsigned*)gate_bits_out : nullptr;
+    a.gbits = (gated == 0 && act == WU_ACT_RELU && !pool) ? (unsigned*)gate_bits_out : nullptr;
+    if (a.gbits) gated = 3;
     const bool nw4 = mode == 2 || (mode == 1 && Cin >= 256);
 #define WU_V2_GO(NW_, G_) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<NW_, G_>), dim3((int)grid), dim3(NW_ * 64), 2 * K::BUF, s, a)
-    if (nw4) { if (gated == 2) WU_V2_GO(4, 2); else if (gated == 1) WU_V2_GO(4, 1); else WU_V2_GO(4, 0); }
-    else { if (gated == 2) WU_V2_GO(8, 2); else if (gated == 1) WU_V2_GO(8, 1); else WU_V2_GO(8, 0); }
+    if (nw4) { if (gated == 3) WU_V2_GO(4, 3); else if (gated == 2) WU_V2_GO(4, 2); else if (gated == 1) WU_V2_GO(4, 1); else WU_V2_GO(4, 0); }
+    else { if (gated == 3) WU_V2_GO(8, 3); else if (gated == 2) WU_V2_GO(8, 2); else if (gated == 1) WU_V2_GO(8, 1); else WU_V2_GO(8, 0); }
 #undef WU_V2_GO
     return 0;
 }
