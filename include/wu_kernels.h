@@ -62,6 +62,10 @@ int wu_set_debug_buffer(void* p);
  * division W/sigma of torch.nn.utils.spectral_norm (nets.py:27-31).  Either output may be NULL. */
 int wu_pack_conv3x3(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin,
                     const float* inv_sigma, int dtype, void* stream);
+/* wu_pack_conv3x3 (no spectral-norm factor) for n <= 16 weights in one launch: entry i packs w_oihw[i] (Cout[i] x Cin[i] x 3 x 3)
+ * into w_fwd[i] and w_dgrad[i].  The pointer / size arrays live in HOST memory and are consumed before the call returns. */
+int wu_pack_conv3x3_multi(int n, const float* const* w_oihw, void* const* w_fwd, void* const* w_dgrad,
+                          const int* Cout, const int* Cin, int dtype, void* stream);
 
 /* Spectral normalisation of a conv weight (torch.nn.utils.spectral_norm around the convs of nets.py:28-31):
  * one power iteration (power_iter != 0: v <- normalize(W^T u), u <- normalize(W v), buffers updated in place),

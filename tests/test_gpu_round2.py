@@ -376,3 +376,82 @@ def test_sndisc_gradients_are_bitwise_reproducible(precision):
         assert torch.equal(gx, runs[0][1])
         for k in g:
             assert torch.equal(g[k], runs[0][0][k]), f"{k} differs between runs"
+
+
+def test_fused_adam_updates_reach_the_convs():
+    """Regression: torch.optim.Adam(fused=True) does not move ``param._version``; the packed MFMA operand images must follow the
+    update anyway.  After two fused-Adam steps the net's output equals that of a FRESH net loaded with the same state-dict, and the
+    packed image of a conv equals its current weight."""
+    import cunet
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    net = cunet.Conditional_UNet(5, precision="bf16").to(dev).train()
+    x = (torch.rand(2, 3, 64, 64, device=dev) * 2 - 1)
+    c = torch.eye(5, device=dev)[torch.arange(2) % 5]
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2, betas=(0.0, 0.999), fused=True)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        net(x, c).abs().mean().backward()
+        opt.step()
+    net.eval()
+    with torch.no_grad():
+        out = net(x, c)
+    conv = net.dconv_down2[0]
+    w = conv.weight.detach()
+    ref = w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(torch.bfloat16)
+    assert torch.equal(conv._packed.w_fwd, ref), "packed operand image is stale after a fused optimizer step"
+    fresh = cunet.Conditional_UNet(5, precision="bf16").to(dev).eval()
+    fresh.load_state_dict(net.state_dict())
+    with torch.no_grad():
+        assert torch.equal(fresh(x, c), out)
+
+
+def test_gate_bit_producers_at_full_size():
+    """The forward kernels that also write gate bits must produce the SAME activations as their plain forms at BASELINE size (B=32
+    256x256): many iterations per wave / many tiles per workgroup, where the prefetch-and-counted-wait machinery is actually
+    exercised (a register-prefetch bug of the 3->64 kernel passed every small-shape test), and the bits must equal (y > 0)."""
+    from wu import kernels as K
+    from wu.layout import empty_nhwc, precision_code
+    dev = torch.device("cuda")
+    code = precision_code("bf16")
+    n = 32
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand((n, 3, 256, 256), generator=g) * 2 - 1).to(dev)
+    w = ((torch.rand((64, 3, 3, 3), generator=g) * 2 - 1) * 0.3).to(dev)
+    b = (torch.rand((64,), generator=g) - 0.5).to(dev)
+    y0 = empty_nhwc(n, 64, 256, 256, torch.bfloat16, dev)
+    K.conv3x3_c3(x, w, b, y0, 1, 1, False, code)
+    for _ in range(2):
+        y1 = empty_nhwc(n, 64, 256, 256, torch.bfloat16, dev)
+        bits = K.gate_bits_alloc(y1)
+        K.conv3x3_c3_bits(x, w, b, y1, bits, 1, code)
+        assert torch.equal(y0, y1)
+        word = bits.view(n, 256, 256, 1, 2)
+        pos = (y1 > 0)
+        for hf in range(2):
+            for k in range(4):
+                for i in range(0, 8, 3):
+                    got = (word[:, :, :, 0, hf] >> (8 * k + i)) & 1
+                    assert torch.equal(got.bool(), pos[:, 16 * k + 8 * hf + i])
+    for (ci, co, h) in [(64, 128, 128), (192, 64, 256), (256, 512, 32)]:
+        xx = empty_nhwc(n, ci, h, h, torch.bfloat16, dev)
+        xx.copy_((torch.rand((n, ci, h, h), generator=g) * 2 - 1).to(dev))
+        ww = ((torch.rand((co, ci, 3, 3), generator=g) * 2 - 1) * 0.05).to(dev)
+        wf, wd = K.pack_conv3x3(ww, code)
+        bb = (torch.rand((co,), generator=g) - 0.5).to(dev)
+        z0 = empty_nhwc(n, co, h, h, torch.bfloat16, dev)
+        K.conv3x3(xx, wf, bb, z0, 1, 1)
+        z1 = empty_nhwc(n, co, h, h, torch.bfloat16, dev)
+        zb = K.gate_bits_alloc(z1)
+        K.conv3x3_bits(xx, wf, bb, z1, 1, gate_bits_out=zb)
+        assert torch.equal(z0, z1)
+        # the data-gradient pass gated by those bits == gated by the tensor
+        gy = empty_nhwc(n, co, h, h, torch.bfloat16, dev)
+        gy.copy_((torch.rand((n, co, h, h), generator=g) * 2 - 1).to(dev))
+        wsq = ((torch.rand((co, co, 3, 3), generator=g) * 2 - 1) * 0.05).to(dev)
+        _, wd2 = K.pack_conv3x3(wsq, code)
+        d0 = empty_nhwc(n, co, h, h, torch.bfloat16, dev)
+        d1 = empty_nhwc(n, co, h, h, torch.bfloat16, dev)
+        K.conv3x3(gy, wd2, None, d0, 1, 0, egate=z1, egate_act=1)
+        K.conv3x3_bits(gy, wd2, None, d1, 0, egate_bits=zb)
+        assert torch.equal(d0, d1)

@@ -138,3 +138,30 @@ def test_resnet_estimator_state_dict_keys_are_torchvisions():
     assert not net.training                                      # frozen for good (t_cls_train.py:173,178)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.zeros(1, 3, 64, 64))
+
+
+def test_packed_weight_cache_follows_optimizer_steps():
+    """torch.optim.Adam(fused=True) updates parameters without moving ``_version`` (measured on the GPU box: 1 -> 1), so the packed
+    operand cache keys on an optimizer-step generation as well: any optimizer.step() makes every PackedConv stale, and so does
+    invalidate_packed(); an in-place update through autograd-visible ops is caught by ``_version`` as before."""
+    import torch
+    from wu import functional as WF
+    w = torch.nn.Parameter(torch.ones(64, 64, 3, 3))
+    pc = WF.PackedConv()
+    pc.key = pc.make_key(w, 1)                       # as if packed now
+    assert not pc.stale(w, 1)
+    w.grad = torch.ones_like(w)
+    torch.optim.SGD([w], lr=0.1).step()
+    assert pc.stale(w, 1)
+    pc.key = pc.make_key(w, 1)
+    # an optimizer that touches OTHER parameters only: still stale (the generation is process-wide; a spare repack is cheap)
+    other = torch.nn.Parameter(torch.ones(3)); other.grad = torch.ones(3)
+    torch.optim.Adam([other], lr=0.1).step()
+    assert pc.stale(w, 1)
+    pc.key = pc.make_key(w, 1)
+    WF.invalidate_packed()
+    assert pc.stale(w, 1)
+    pc.key = pc.make_key(w, 1)
+    with torch.no_grad():
+        w.add_(1.0)
+    assert pc.stale(w, 1)

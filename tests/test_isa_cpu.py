@@ -1,0 +1,69 @@
+"""Generated-code check for the one kernel that prefetches into REGISTERS from inline asm (conv3x3_c3_fwd_mfma_kernel, csrc/thin.hip).
+
+The next block's 16 patch values are requested by `buffer_load_dword` asm statements and retired by one counted `s_waitcnt` asm; the
+compiler does not know the loads are asynchronous.  If register allocation ever puts a copy (or any other read) of a destination
+register between its load and the wait, the kernel silently computes on the previous block's patch -- which only shows at sizes with
+more than one iteration per wave.  This test cross-compiles the file to gfx950 assembly (no GPU needed) and checks, for every
+instance, that inside the main loop no instruction reads a load's destination register between that load and the loop's wait."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_c3_forward_prefetch_registers_are_not_read_before_the_wait(tmp_path):
+    src = os.path.join(ROOT, "weather-unet_amd", "csrc", "thin.hip")
+    out = str(tmp_path / "thin.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I", os.path.join(ROOT, "include"),
+                    "-S", "--cuda-device-only", src, "-o", out], check=True, capture_output=True, timeout=900)
+    text = open(out).read().splitlines()
+    starts = [i for i, l in enumerate(text) if re.match(r"^_ZN.*conv3x3_c3_fwd_mfma_kernel[^.]*:", l)]       # code labels, not the .kd descriptors
+    assert len(starts) >= 8
+    checked = 0
+    for st in starts:
+        end = next(i for i in range(st, len(text)) if "s_endpgm" in text[i])
+        body = text[st:end]
+        loads = [(i, re.search(r"buffer_load_dword (v\d+),", l).group(1)) for i, l in enumerate(body) if "buffer_load_dword v" in l and "offen" in l]
+        # the in-loop group: the LAST 16 asm loads of the function; the loop's wait: the first counted / full vmcnt wait after them
+        assert len(loads) >= 32, "expected the pre-loop and the in-loop patch gathers"
+        group = loads[-16:]
+        first, last = group[0][0], group[-1][0]
+        # the loop around them: every label annotated "Loop Header" / "in Loop" next to the loads; it ends at the first label after
+        # the loads that is not part of it.  The block with the wait may be laid out BEFORE the header (rotated loop): then the path
+        # load -> wait runs to the end of the loop and continues at its first block.
+        labels = [(i, l) for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)]
+        in_loop = [i for i, l in labels if "Loop" in l]
+        loop_start = max([i for i in in_loop if i < first and all("Loop" in l for j, l in labels if i <= j < first)] or [first], key=lambda i: -i)
+        after = [i for i, l in labels if i > last and "Loop" not in l]
+        loop_end = after[0] if after else len(body)
+        is_wait = lambda i: re.search(r"s_waitcnt vmcnt\(\d+\)", body[i]) is not None
+        fwd = [i for i in range(last, loop_end) if is_wait(i)]
+        if fwd:
+            wait, path = fwd[0], lambda at: list(range(at + 1, fwd[0]))
+        else:
+            early = [i for i in range(loop_start, first) if is_wait(i)]
+            assert early, "no vmcnt wait on the loop path after the patch loads"
+            wait, path = early[0], lambda at: list(range(at + 1, loop_end)) + list(range(loop_start, early[0]))
+        dests = {}
+        for i, reg in group:
+            dests[reg] = i
+        assert len(dests) == 16, "two loads share a destination register"
+        for reg, at in dests.items():
+            n = int(reg[1:])
+            for i in path(at):
+                line = body[i].split(";")[0]
+                m = re.match(r"\s*(\S+)\s+(.*)", line)
+                if not m or m.group(1).startswith(".") or m.group(1).endswith(":"):
+                    continue
+                ops = [o.strip() for o in m.group(2).split(",")]
+                for o in ops[1:]:                     # source operands (single registers and ranges v[a:b])
+                    rng = re.match(r"v\[(\d+):(\d+)\]", o)
+                    if o == reg or (rng and int(rng.group(1)) <= n <= int(rng.group(2))):
+                        raise AssertionError(f"{text[st][:70]}...: `{body[i].strip()}` reads {reg} before the wait (load at +{at}, wait at +{wait})")
+        checked += 1
+    assert checked == len(starts)

@@ -79,10 +79,10 @@ __device__ __forceinline__ uint32_t max_u16x2(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t nonzero_byte(const uint4& v) {
     uint32_t t0, t1, t2, t3;
     const uint32_t one = 0x00010001u;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t0) : "v"(v.x), "v"(one));
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t1) : "v"(v.y), "v"(one));
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t2) : "v"(v.z), "v"(one));
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t3) : "v"(v.w), "v"(one));
+    asm("v_pk_min_u16 %0, %1, %2" : "=&v"(t0) : "v"(v.x), "v"(one));
+    asm("v_pk_min_u16 %0, %1, %2" : "=&v"(t1) : "v"(v.y), "v"(one));
+    asm("v_pk_min_u16 %0, %1, %2" : "=&v"(t2) : "v"(v.z), "v"(one));
+    asm("v_pk_min_u16 %0, %1, %2" : "=&v"(t3) : "v"(v.w), "v"(one));
     const uint32_t xx = ((t3 << 6) | t2 << 4) | ((t1 << 2) | t0);
     return (xx | (xx >> 15)) & 0xffu;
 }

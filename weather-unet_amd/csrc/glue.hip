@@ -25,6 +25,34 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__
     }
 }
 
+// The same repack for up to 16 weights in ONE launch (a generator forward after an optimizer step repacks all 13 of its MFMA conv
+// weights: 13 launches of ~8 us each with the queue's dependency gap between them, against one of ~20 us).  Block b belongs to the
+// weight whose block range contains it (prefix sums in the argument struct).
+struct PackMulti {
+    const float* w[16]; void* wf[16]; void* wd[16];
+    int cout[16], cin[16], first_block[17];
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv3x3_multi_kernel(const PackMulti a) {
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < 16; ++i) k += (i < a.n && (int)blockIdx.x >= a.first_block[i]) ? 1 : 0;
+    const int Cout = a.cout[k], Cin = a.cin[k];
+    const int idx = ((int)blockIdx.x - a.first_block[k]) * 256 + threadIdx.x;
+    if (idx >= Cout * Cin) return;
+    const int co = idx / Cin, ci = idx - co * Cin;
+    const float* src = a.w[k] + (size_t)idx * 9;
+    T* wf = (T*)a.wf[k];
+    T* wd = (T*)a.wd[k];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float v = src[t];
+        ElemTraits<T>::store(wf + ((size_t)t * Cout + co) * Cin + ci, v);
+        ElemTraits<T>::store(wd + ((size_t)(8 - t) * Cin + ci) * Cout + co, v);
+    }
+}
+
 // =================================================================================================
 // MaxPool2d(2)   (cunet.py:27)
 // =================================================================================================
@@ -917,6 +945,26 @@ extern "C" int wu_pack_conv3x3(const float* w_oihw, void* w_fwd, void* w_dgrad, 
     DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv3x3_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
                                          w_oihw, (T*)w_fwd, (T*)w_dgrad, Cout, Cin, inv_sigma));
     WU_LAUNCH_CHECK("pack_conv3x3");
+    return 0;
+}
+
+extern "C" int wu_pack_conv3x3_multi(int n, const float* const* w_oihw, void* const* w_fwd, void* const* w_dgrad,
+                                     const int* Cout, const int* Cin, int dtype, void* stream) {
+    WU_REQUIRE(n >= 1 && n <= 16 && w_oihw && w_fwd && w_dgrad && Cout && Cin, "pack_conv3x3_multi: 1..16 weights per call");
+    PackMulti a;
+    a.n = n;
+    long long blocks = 0;
+    for (int i = 0; i < 16; ++i) {
+        const int j = i < n ? i : n - 1;
+        WU_REQUIRE(w_oihw[j] && w_fwd[j] && w_dgrad[j] && Cout[j] > 0 && Cin[j] > 0, "pack_conv3x3_multi: bad entry %d", j);
+        a.w[i] = w_oihw[j]; a.wf[i] = w_fwd[j]; a.wd[i] = w_dgrad[j]; a.cout[i] = Cout[j]; a.cin[i] = Cin[j];
+        a.first_block[i] = (int)blocks;
+        if (i < n) blocks += ((long long)Cout[j] * Cin[j] + 255) / 256;
+    }
+    a.first_block[16] = (int)blocks;
+    WU_REQUIRE(blocks < (1ll << 31), "pack_conv3x3_multi: too many elements");
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv3x3_multi_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a));
+    WU_LAUNCH_CHECK("pack_conv3x3_multi");
     return 0;
 }
 

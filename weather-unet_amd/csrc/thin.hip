@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(const float* __rest
 // kernel.  Accumulators are transposed (lane owns 4 consecutive channels of its pixel); the epilogue transposes through a
 // wave-private LDS patch (no barrier) so the stores cover whole pixel rows.  The VALU form above needs
 // 1728 fp32 FMAs per pixel (fp32 VALU peak = 1/16 of the bf16 matrix rate); this one is bound by the 268 MB it writes.
-template <int STRIDE, int ACT, bool FULL>
+// BITS: also write the gate bits of the output (ACT == RELU).  A template flag, not a run-time one: the loop must end in exactly ONE
+// counted-wait asm statement (see below).
+template <int STRIDE, int ACT, bool FULL, bool BITS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv3x3_c3_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, const float* __restrict__ inv_sigma,
                                                                   bf16_t* __restrict__ y, int ldy, int N, int H, int W,
@@ -182,25 +184,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             const uint4 v4 = *(const uint4*)(tp + r * 144 + sl * 16);
             // FULL (total % 32 == 0): unconditional stores.  Behind a branch the compiler cannot count them and waits vmcnt(0)
             // -- their write acknowledgements -- before it touches the prefetched patch at the top of the next iteration.
-            if (FULL || p2 < total) *(uint4*)(y + (size_t)p2 * ldy + sl * 8) = v4;
-            if (ACT == WU_ACT_RELU && gbits && (FULL || p2 < total)) {
-                // gate bits (wu_kernels.h): this lane's 8 channels 8 sl .. 8 sl + 7 are byte sl >> 1 of word (pixel, 0, sl & 1)
+            // gate bits (wu_kernels.h): this lane's 8 channels 8 sl .. 8 sl + 7 are byte sl >> 1 of word (pixel, 0, sl & 1).  Computed
+            // BEFORE the 16-byte store is issued: placed after it, the VALU results were allocated onto the store's address / data
+            // registers and the stored rows came out corrupted at full size (more than one iteration per wave) although the
+            // compiler's hazard rules were met -- nothing may write those registers while the store is young.
+            uint32_t gate_byte = 0;
+            if (BITS) {
                 uint32_t t0, t1, t2, t3;
                 const uint32_t one = 0x00010001u;          // v_pk_min_u16 with 1: 0/1 per non-negative bf16 half (see conv3x3_mfma_v2.hip)
-                asm("v_pk_min_u16 %0, %1, %2" : "=v"(t0) : "v"(v4.x), "v"(one));
-                asm("v_pk_min_u16 %0, %1, %2" : "=v"(t1) : "v"(v4.y), "v"(one));
-                asm("v_pk_min_u16 %0, %1, %2" : "=v"(t2) : "v"(v4.z), "v"(one));
-                asm("v_pk_min_u16 %0, %1, %2" : "=v"(t3) : "v"(v4.w), "v"(one));
+                asm("v_pk_min_u16 %0, %1, %2" : "=&v"(t0) : "v"(v4.x), "v"(one));
+                asm("v_pk_min_u16 %0, %1, %2" : "=&v"(t1) : "v"(v4.y), "v"(one));
+                asm("v_pk_min_u16 %0, %1, %2" : "=&v"(t2) : "v"(v4.z), "v"(one));
+                asm("v_pk_min_u16 %0, %1, %2" : "=&v"(t3) : "v"(v4.w), "v"(one));
                 const uint32_t xx = t0 | (t1 << 2) | (t2 << 4) | (t3 << 6);
-                gbits[(size_t)p2 * 8 + (sl & 1) * 4 + (sl >> 1)] = (unsigned char)((xx | (xx >> 15)) & 0xffu);
+                gate_byte = (xx | (xx >> 15)) & 0xffu;
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (FULL || p2 < total) *(uint4*)(y + (size_t)p2 * ldy + sl * 8) = v4;
+            if (BITS && (FULL || p2 < total)) gbits[(size_t)p2 * 8 + (sl & 1) * 4 + (sl >> 1)] = (unsigned char)gate_byte;
+            __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_wave_barrier();
-        // the next block's patch has landed (the registers named here are exactly the asm loads' destinations)
-        // (with gate bits every store is followed by a byte store: eight younger operations instead of four)
-        if (FULL && ACT == WU_ACT_RELU && gbits) asm volatile("s_waitcnt vmcnt(8)" : WU_V16(vn) : : "memory");
-        else if (FULL) asm volatile("s_waitcnt vmcnt(4)" : WU_V16(vn) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : WU_V16(vn) : : "memory");
+        // The next block's patch has landed.  ONE asm statement with a compile-time count: its tied operands must be the very
+        // registers the asm loads wrote.  With several alternative wait statements (run-time if / else) the register allocator
+        // copies the patch registers into each statement's operands BEFORE the wait -- i.e. before the data has arrived -- and the
+        // kernel computes on the previous block's patch (found at full size only: one iteration per wave hides it).
+        // tests/test_isa_cpu.py checks in the generated code that nothing reads those registers between the loads and the wait.
+        // vmcnt(4) leaves this iteration's four stores in flight, vmcnt(8) the four stores + four gate-byte stores.
+        asm volatile("s_waitcnt vmcnt(%16)" : WU_V16(vn) : "n"(FULL ? (BITS ? 8 : 4) : 0) : "memory");
     }
 #undef WU_V16
 }
@@ -961,8 +972,10 @@ static int c3_fwd_impl(const float* x_nchw, const float* w_oihw, const float* bi
     const int grid_l = grid_cap((long long)N * Ho * Wo, 256, 256 * 8);
     // fp32 path: the LDS-broadcast one-thread-per-pixel kernel (239 us at B=32 256x256 in bf16 storage; the scalar-weight /
     // transposed-store variant conv3x3_c3_fwd_rows_kernel measured 326 us and is kept selectable for A/B work)
-#define C3_MFMA_F(ST, A, F) hipLaunchKernelGGL((conv3x3_c3_fwd_mfma_kernel<ST, A, F>), dim3(grid_m), dim3(256), 0, s, x_nchw, w_oihw, bias, inv_sigma, (bf16_t*)y, ldy, N, H, W, (unsigned char*)gate_bits_out)
-#define C3_MFMA_A(ST, A) do { if (((long long)N * Ho * Wo) % 32 == 0) C3_MFMA_F(ST, A, true); else C3_MFMA_F(ST, A, false); } while (0)
+#define C3_MFMA_F(ST, A, F, B) hipLaunchKernelGGL((conv3x3_c3_fwd_mfma_kernel<ST, A, F, B>), dim3(grid_m), dim3(256), 0, s, x_nchw, w_oihw, bias, inv_sigma, (bf16_t*)y, ldy, N, H, W, (unsigned char*)gate_bits_out)
+#define C3_MFMA_A(ST, A) do { const bool full_ = ((long long)N * Ho * Wo) % 32 == 0;                                              \
+        if (gate_bits_out && A == WU_ACT_RELU) { if (full_) C3_MFMA_F(ST, WU_ACT_RELU, true, true); else C3_MFMA_F(ST, WU_ACT_RELU, false, true); } \
+        else { if (full_) C3_MFMA_F(ST, A, true, false); else C3_MFMA_F(ST, A, false, false); } } while (0)
 #define C3_MFMA(ST) do { if (act == WU_ACT_RELU) C3_MFMA_A(ST, WU_ACT_RELU); else if (act == WU_ACT_LEAKY) C3_MFMA_A(ST, WU_ACT_LEAKY); else C3_MFMA_A(ST, WU_ACT_NONE); } while (0)
     const int grid_m = grid_cap((long long)N * Ho * Wo, 128, 256 * 16);
     // option 5: 0 = bf16 on the matrix cores (default), 1 = scalar-weight rows kernel, 2 = one-thread-per-pixel VALU kernel

@@ -24,9 +24,32 @@ def _grad_nhwc(g, code):
 # ----------------------------------------------------------------------------------------------
 # packed weights
 # ----------------------------------------------------------------------------------------------
+# A weight can change without its ``_version`` moving: ``torch.optim.Adam(fused=True)`` (and the other fused / capturable
+# optimizers) update parameters through ``torch._fused_adam_``, which does NOT bump the version counter (measured: version 1 -> 1
+# across steps, while the foreach / single-tensor paths go 1 -> 2 -> 3).  A cache keyed on (storage, version) alone would then keep
+# handing the convs the weights of step 0.  Every optimizer step therefore bumps a process-wide generation that is part of the
+# key: after ANY ``optimizer.step()`` every packed image is rebuilt on its next use (13 small launches per generator forward,
+# batched into one by ``repack_stale``).  Updates made outside ``torch.optim`` with ops that skip the version counter must call
+# ``invalidate_packed()``.
+_WEIGHT_GENERATION = [0]
+
+
+def invalidate_packed():
+    """Force every PackedConv to rebuild on its next use (weights were changed behind autograd's version counter)."""
+    _WEIGHT_GENERATION[0] += 1
+
+
+def _on_optimizer_step(optimizer, args, kwargs):
+    invalidate_packed()
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+_STEP_HOOK = _register_step_hook(_on_optimizer_step)
+
+
 class PackedConv:
     """[tap][Cout][Cin] (forward) and [tap'][Cin][Cout] (data-gradient) MFMA operand images of one
-    OIHW fp32 weight, cached on (storage, version, dtype) so a weight is repacked once per update.
+    OIHW fp32 weight, cached on (storage, version, optimizer-step generation, dtype) so a weight is repacked once per update.
 
     ``ident``: when `weight` is a TEMPORARY derived from a parameter (the spectral-norm W/sigma of nets.SNConv3x3, a fresh
     tensor per forward whose storage the caching allocator hands out again at the same point of the next iteration), its
@@ -38,14 +61,33 @@ class PackedConv:
         self.w_fwd = None
         self.w_dgrad = None
 
-    def get(self, weight, code, ident=None):
+    @staticmethod
+    def make_key(weight, code, ident=None):
         if ident is None:
             ident = (weight.data_ptr(), weight._version)
-        key = (ident, code, tuple(weight.shape))
+        return (ident, _WEIGHT_GENERATION[0], code, tuple(weight.shape))
+
+    def stale(self, weight, code, ident=None):
+        return self.make_key(weight, code, ident) != self.key
+
+    def get(self, weight, code, ident=None):
+        key = self.make_key(weight, code, ident)
         if key != self.key:
             self.w_fwd, self.w_dgrad = K.pack_conv3x3(weight, code)
             self.key = key
         return self.w_fwd, self.w_dgrad
+
+
+def repack_stale(pairs, code):
+    """Rebuild, in ONE launch, the packed images of every (PackedConv, weight) pair whose key is out of date."""
+    todo = [(pc, w) for pc, w in pairs if pc.stale(w, code)]
+    if not todo:
+        return 0
+    outs = K.pack_conv3x3_multi([w for _, w in todo], code)
+    for (pc, w), (wf, wd) in zip(todo, outs):
+        pc.w_fwd, pc.w_dgrad = wf, wd
+        pc.key = pc.make_key(w, code)
+    return len(todo)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -77,12 +77,16 @@ class GraphedUNet:
             blk = getattr(net, name)
             for conv in (blk[0], blk[2]):
                 self._held.append((conv._packed.w_fwd, conv._packed.w_dgrad))
-        self._versions = tuple(p._version for p in self._params())
+        # fused optimizers update parameters without moving ``_version`` (wu.functional): the optimizer-step generation is part of
+        # the freshness test
+        from .functional import _WEIGHT_GENERATION
+        self._versions = (_WEIGHT_GENERATION[0],) + tuple(p._version for p in self._params())
         self._ptrs = tuple(p.data_ptr() for p in self._params())
 
     def _check_fresh(self):
         ps = self._params()
-        if tuple(p._version for p in ps) != self._versions or tuple(p.data_ptr() for p in ps) != self._ptrs:
+        from .functional import _WEIGHT_GENERATION
+        if (_WEIGHT_GENERATION[0],) + tuple(p._version for p in ps) != self._versions or tuple(p.data_ptr() for p in ps) != self._ptrs:
             self._capture()            # weights changed since capture: re-pack + re-capture (never replay stale operands)
 
     def __call__(self, x, c, copy_out=False):

@@ -251,6 +251,29 @@ def l1_mean(a, b, want_grad):
     return loss, grad
 
 
+def pack_conv3x3_multi(weights, code):
+    """pack_conv3x3 for a list of OIHW fp32 weights in one launch (wu_pack_conv3x3_multi, <= 16 weights per launch)."""
+    import ctypes
+    from .layout import torch_dtype
+    tdt = torch_dtype(code)
+    outs, ws = [], []
+    for weight in weights:
+        cout, cin = weight.shape[:2]
+        w = weight.detach()
+        w = w if w.is_contiguous() else w.contiguous()
+        ws.append(w)
+        outs.append((torch.empty((9, cout, cin), dtype=tdt, device=weight.device), torch.empty((9, cin, cout), dtype=tdt, device=weight.device)))
+    for i in range(0, len(ws), 16):
+        chunk = list(range(i, min(i + 16, len(ws))))
+        n = len(chunk)
+        P = ctypes.c_void_p * n
+        I = ctypes.c_int * n
+        _lib.call("wu_pack_conv3x3_multi", n, P(*[ws[j].data_ptr() for j in chunk]), P(*[outs[j][0].data_ptr() for j in chunk]),
+                  P(*[outs[j][1].data_ptr() for j in chunk]), I(*[ws[j].shape[0] for j in chunk]), I(*[ws[j].shape[1] for j in chunk]),
+                  code, stream_ptr())
+    return outs
+
+
 def pack_conv3x3(weight, code):
     """(w_fwd [9][Cout][Cin], w_dgrad [9][Cin][Cout]) in the compute dtype."""
     from .layout import torch_dtype

@@ -149,7 +149,11 @@ class ResNet101Estimator(nn.Module):
     # ---- folded / packed operands, rebuilt when a tensor of the state changes ----
     def _state_key(self):
         ts = list(self.parameters()) + list(self.buffers())
-        return (self.precision,) + tuple((t.data_ptr(), t._version) for t in ts)
+        # a TRAINABLE estimator may be updated by a fused optimizer, which does not move ``_version`` (wu.functional): then the
+        # optimizer-step generation joins the key; the frozen estimator of the GAN loop keeps its plan across G / D steps
+        from .functional import _WEIGHT_GENERATION
+        gen = _WEIGHT_GENERATION[0] if any(p.requires_grad for p in self.parameters()) else 0
+        return (self.precision, gen) + tuple((t.data_ptr(), t._version) for t in ts)
 
     def plan(self):
         key = self._state_key()

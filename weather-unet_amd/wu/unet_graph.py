@@ -149,6 +149,14 @@ class UNetFn(Function):
         P = list(params)
         wb = {name: (P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]) for i, name in enumerate(BLOCKS)}
         w_last, b_last = P[28], P[29]
+        # after an optimizer step every packed operand image is out of date: rebuild them all in one launch
+        from .functional import repack_stale
+        stale = []
+        for i, name in enumerate(BLOCKS):
+            if name != "dconv_down1":
+                stale.append((packed[2 * i], wb[name][0]))
+            stale.append((packed[2 * i + 1], wb[name][2]))
+        repack_stale(stale, code)
         pk = {}                                  # (w_fwd, w_dgrad) per MFMA conv
         for i, name in enumerate(BLOCKS):
             w0, _, w2, _ = wb[name]
