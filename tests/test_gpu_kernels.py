@@ -556,3 +556,18 @@ def test_conv3x3_c3_gate_bits():
     K.conv3x3_c3_bits(x, wt, b, y1, bits, 1, code)
     assert torch.equal(y0, y1)
     assert torch.equal(_decode_gate_bits(bits, n, 64, h, w), (y0.float() > 0).cpu())
+
+
+@pytest.mark.parametrize("p", DTYPES)
+def test_pack_conv3x3_multi_equals_single(p):
+    """The batched repack (one launch for all stale weights after an optimizer step) writes the same two operand images as the
+    per-weight kernel, ragged channel counts included."""
+    from wu import kernels as K
+    from wu.layout import precision_code
+    code = precision_code(p)
+    ws = [_rand(shape, 300 + i, -0.2, 0.2).to(_dev()) for i, shape in enumerate(
+        [(64, 64, 3, 3), (128, 64, 3, 3), (64, 192, 3, 3), (256, 768, 3, 3), (48, 80, 3, 3), (16, 16, 3, 3)] + [(64, 64, 3, 3)] * 12)]
+    outs = K.pack_conv3x3_multi(ws, code)          # 18 weights: two launches
+    for w, (wf, wd) in zip(ws, outs):
+        rf, rd = K.pack_conv3x3(w, code)
+        assert torch.equal(wf, rf) and torch.equal(wd, rd)
