@@ -455,3 +455,39 @@ def test_gate_bit_producers_at_full_size():
         K.conv3x3(gy, wd2, None, d0, 1, 0, egate=z1, egate_act=1)
         K.conv3x3_bits(gy, wd2, None, d1, 0, egate_bits=zb)
         assert torch.equal(d0, d1)
+
+
+def test_three_step_trajectory_fused_vs_foreach_adam():
+    """Multi-step parity: three Adam steps with the fused optimizer (no `_version` bump) and with the foreach optimizer (bumps it)
+    must walk the same trajectory -- same losses, same parameters to fp32 rounding -- i.e. every forward sees the weights the last
+    step wrote.  (Single-step oracle parity cannot see a stale operand cache; this can.)"""
+    import cunet
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(21)
+    x = (torch.rand((2, 3, 64, 64), generator=g) * 2 - 1).to(dev)
+    c = torch.eye(5)[torch.arange(2) % 5].to(dev)
+
+    def run(fused):
+        torch.manual_seed(4)
+        net = cunet.Conditional_UNet(5, precision="fp32").to(dev).train()
+        net.dropout_seed = 9
+        opt = torch.optim.Adam(net.parameters(), lr=2e-3, betas=(0.0, 0.999), fused=fused, foreach=None if fused else True)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = (net(x, c) - x).abs().mean()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        return losses, {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+    la, pa = run(True)
+    lb, pb = run(False)
+    assert la[0] == lb[0]
+    assert all(abs(a - b) <= 1e-5 * max(1.0, abs(b)) for a, b in zip(la, lb)), (la, lb)
+    assert la[2] < la[0]
+    # beta1 = 0: an element's step is lr * g / (|g| + eps), ill-conditioned where g ~ 0, so single elements may differ by a fraction
+    # of a step between the two optimizer implementations; the bulk must agree to rounding
+    for k in pa:
+        d = (pa[k].float() - pb[k].float()).abs()
+        assert d.max().item() <= 1.5e-3 and d.mean().item() <= 2e-5, f"{k}: fused and foreach Adam trajectories differ (max {d.max().item()}, mean {d.mean().item()})"
