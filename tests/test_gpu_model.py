@@ -544,3 +544,66 @@ def test_step_shares_the_estimator_forwards(mode):
         res.append([t.item() for t in out])
     for a, b in zip(*res):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), res
+
+
+def test_gan_two_iterations_match_oracle():
+    """Two FULL iterations (D update + G update, real Adam steps, lr 1e-3) of the t_cls_train loop against the oracle driven by
+    stock torch.optim.Adam on the CPU: the second iteration's losses depend on every weight the first one wrote -- G's packed conv
+    operands, D's spectral-norm weights and power-iteration buffers -- so a stale cache anywhere shows up here (the single-step
+    test above runs with lr = 0 and cannot see it)."""
+    from wu.train_step import WeatherTransferStep, StandInEstimator
+    nc, seed, batch, size, lr = 5, 9, 2, 64, 1e-3
+    st = WeatherTransferStep(nc, mode="cls", precision="fp32", lr=lr, device=DEV, ddp=False, seed=1)
+    st.inference.load_state_dict(O.make_cunet_params(nc, seed))
+    st.discriminator.load_state_dict(O.make_sndisc_params(nc, seed))
+    st.inference.eval()                        # dropout identity so the oracle needs no mask
+    x, _ = O.make_inputs(batch, size, nc, seed, True)
+    xr, _ = O.make_inputs(batch, size, nc, seed + 1, True)
+    est_cpu = StandInEstimator(nc)
+    est_cpu.load_state_dict({k: v.cpu() for k, v in st.estimator_.state_dict().items()})
+    est_out = lambda t: torch.softmax(est_cpu(t), 1)
+    gp = {k: v.clone().requires_grad_(True) for k, v in O.make_cunet_params(nc, seed).items()}
+    dp = {k: (v.clone().requires_grad_(True) if k.endswith(("weight_orig", "bias")) else v.clone())
+          for k, v in O.make_sndisc_params(nc, seed).items()}
+    wd = st.g_opt.param_groups[0]["weight_decay"]
+    g_ref_opt = torch.optim.Adam([v for v in gp.values()], lr=lr, betas=(0.0, 0.999), weight_decay=wd)
+    d_ref_opt = torch.optim.Adam([v for v in dp.values() if v.requires_grad], lr=lr, betas=(0.0, 0.999), weight_decay=wd)
+    with torch.no_grad():
+        rand_labels = est_out(xr)
+    xd, rl = x.to(DEV), rand_labels.to(DEV)
+    for it in range(2):
+        # ---- oracle iteration ----
+        d_ref_opt.zero_grad(set_to_none=True)
+        d_loss_ref, nb2 = O.update_discriminator_loss(gp, dp, est_out, x, rand_labels, None, False)
+        for v in gp.values():
+            v.grad = None
+        d_loss_ref.backward()
+        d_ref_opt.step()
+        with torch.no_grad():
+            for k, v in nb2.items():
+                dp[k] = v.clone()
+        g_ref_opt.zero_grad(set_to_none=True)
+        g_ref = O.update_inference_loss(gp, dp, est_out, est_cpu, x, rand_labels, None, None, False, False)
+        g_ref[0].backward()
+        g_ref_opt.step()
+        with torch.no_grad():                    # the power iteration of the G update's D forward (independent of the input)
+            nb3 = O.sndisc_forward({k: v.detach() for k, v in dp.items()}, x, rand_labels, train=True)[1]
+            for k, v in nb3.items():
+                dp[k] = v.clone()
+        # ---- build ----
+        d_loss = st.update_discriminator(xd, rl, None)
+        g_losses = st.update_inference(xd, rl, None, None)
+        d_err = abs(d_loss.item() - d_loss_ref.item()) / max(1.0, abs(d_loss_ref.item()))
+        g_err = abs(g_losses[0].item() - g_ref[0].item()) / max(1.0, abs(g_ref[0].item()))
+        print(f"GAN iteration {it}: d_loss {d_loss.item():.6f} vs {d_loss_ref.item():.6f}, g_loss {g_losses[0].item():.6f} vs {g_ref[0].item():.6f}")
+        assert d_err <= 3e-3 and g_err <= 3e-3, (it, d_err, g_err)
+    # the weights themselves after two iterations: Adam with beta1 = 0 steps lr * g / (|g| + eps) per element -- where g ~ 0 the sign
+    # differs between implementations, so single elements may be up to 2 * 2 * lr apart; the UPDATE as a whole must agree
+    init = O.make_cunet_params(nc, seed)
+    for k, prm in st.inference.named_parameters():
+        if gp[k].grad is None:
+            continue
+        da = (prm.detach().cpu() - init[k]).reshape(-1).double()
+        db = (gp[k].detach() - init[k]).reshape(-1).double()
+        cos = (torch.dot(da, db) / (da.norm() * db.norm() + 1e-30)).item()
+        assert cos >= 0.9 and (da - db).abs().mean().item() <= 0.2 * lr, (k, cos, (da - db).abs().mean().item())
