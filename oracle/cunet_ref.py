@@ -383,26 +383,39 @@ def update_inference_loss(gp, dp, estimator_out, estimator_raw, images, r_labels
     return g_loss, g_loss_adv, loss_con, g_loss_w, g_loss_l1, fake_out
 
 
-def evaluation(gp, dp, estimator_out, estimator_eval, images, labels, ref_labels):
+def evaluation(gp, dp, estimator_out, estimator_eval, images, labels, ref_labels, d_train=False, masks=None):
     """t_cls_train.py:314-367 / t_est_train.py:285-332: for every reference row i, transfer the whole test batch to
     ref_labels[i] and average four losses over the B passes.  ``estimator_eval`` is ``self.estimator_`` (raw outputs) in
     t_cls_train (:338) and ``self.estimator`` in t_est_train (:309).  The scripts never call .eval(): G's dropout and D's
-    power iteration stay active there; this restatement takes the deterministic part (eval-mode G, D buffers frozen).
-    Returns (dict of the four means, list of the B fake batches)."""
+    power iteration stay active there.  ``d_train=True`` is that mode for D: each of the 2*B discriminator forwards
+    (:340-341, under no_grad -- the spectral-norm hook iterates whenever ``module.training``, whatever the grad mode)
+    advances weight_u / weight_v once, so every pass sees a slightly different W/sigma and D's buffers -- training state --
+    have moved 2*B iterations when the sweep returns.  ``masks``: optional list of B dropout-mask triples for G's passes
+    (train-mode G); None = eval-mode G (the deterministic part).
+    Returns (dict of the four means, list of the B fake batches[, D's buffers after the sweep if d_train])."""
     bs, nc = images.shape[0], ref_labels.shape[1]
     adv, l1, w, d = [], [], [], []
     fakes = []
+    dp = dict(dp)
     with torch.no_grad():
         for i in range(bs):
             ref_expand = torch.cat([ref_labels[i]] * bs).view(-1, nc)                   # :336
-            fake = cunet_forward(gp, images, ref_expand)                                # :337
+            fake = cunet_forward(gp, images, ref_expand, None if masks is None else masks[i])   # :337
             fake_c = estimator_eval(fake)                                               # :338
-            real_d = sndisc_forward(dp, images, labels, train=False)[0][0]              # :340
-            fake_d = sndisc_forward(dp, fake, ref_expand, train=False)[0][0]            # :341
+            real_o, nb = sndisc_forward(dp, images, labels, train=d_train)              # :340
+            if d_train:
+                dp.update(nb)
+            fake_o, nb = sndisc_forward(dp, fake, ref_expand, train=d_train)            # :341
+            if d_train:
+                dp.update(nb)
+            real_d, fake_d = real_o[0], fake_o[0]
             fakes.append(fake)
             adv.append(gen_hinge(fake_d).item())                                        # :349
             l1.append(F.l1_loss(fake, images).item())                                   # :350
             w.append(pred_loss(fake_c, ref_expand).item())                              # :351
             d.append(dis_hinge(fake_d, real_d).item())                                  # :352
-    return {"g_loss_adv": float(np.mean(adv)), "g_loss_l1": float(np.mean(l1)), "g_loss_w": float(np.mean(w)),
-            "d_loss": float(np.mean(d))}, fakes
+    means = {"g_loss_adv": float(np.mean(adv)), "g_loss_l1": float(np.mean(l1)), "g_loss_w": float(np.mean(w)),
+             "d_loss": float(np.mean(d))}
+    if d_train:
+        return means, fakes, {k: v for k, v in dp.items() if k.endswith(("weight_u", "weight_v"))}
+    return means, fakes

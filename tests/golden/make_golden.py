@@ -30,6 +30,7 @@ for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.fu
 sys.path.insert(0, "/root/reference")
 import cunet as ref_cunet  # noqa: E402  (the reference)
 import disc as ref_disc    # noqa: E402
+import ops as ref_ops      # noqa: E402
 
 from oracle import cunet_ref as O  # noqa: E402
 
@@ -182,15 +183,165 @@ def gen_disc(tag, batch, size, seed):
     print(f"sndisc_{tag}: out {outs[0].detach().reshape(-1)[:4].numpy()} loss {loss.item():.5f}")
 
 
+def gen_disc_default_init(tag, batch, size, seed):
+    """torch.manual_seed(seed); SNDisc(nc): the reference's effective default init (disc.py:16-25: xavier_uniform_ through the
+    storage-sharing `.weight` attribute), per-key checksums + one train-mode forward (output and moved buffers)."""
+    torch.manual_seed(seed)
+    net = ref_disc.SNDisc(NC)
+    net.train()
+    p = {k: v.clone() for k, v in net.state_dict().items()}
+    x, c = O.make_inputs(batch, size, NC, seed, True)
+    with torch.no_grad():
+        outs = net(x, c)
+        outs_o, nb = O.sndisc_forward(p, x, c, train=True)
+    exact(outs[0], outs_o[0], f"{tag} default-init D output")
+    sd = net.state_dict()
+    for k, v in nb.items():
+        exact(sd[k], v, f"{tag} buffer {k}")
+    keys = sorted(p)
+    chk = np.array([[p[k].double().sum().item(), p[k].double().abs().sum().item(), p[k].reshape(-1)[0].item(),
+                     p[k].abs().max().item()] for k in keys])
+    np.savez_compressed(os.path.join(OUT, f"sndisc_{tag}.npz"), meta=np.array([batch, size, 1, seed, NC]),
+                        out=outs[0].numpy(), keys=np.array(keys), checksums=chk)
+    print(f"sndisc_{tag}: default-init out {outs[0].reshape(-1)[:3].numpy()}")
+
+
+def periodic_fill(shapes, seed, bounds):
+    """Checkpoint-fixture weights: each tensor reads a 4093-entry table of U(-1,1) values cyclically from a key-dependent
+    offset, times a per-tensor bound.  4093 is prime (no alignment with any tensor dimension, so a transposed / permuted load
+    cannot go unnoticed) and 16 KiB of period keeps the 40-MB checkpoint a few hundred KB under gzip."""
+    import zlib
+    table = torch.from_numpy(np.random.default_rng([77, seed]).uniform(-1, 1, 4093).astype(np.float32))
+    out = {}
+    for k, shp in sorted(shapes.items()):
+        n = int(np.prod(shp))
+        idx = (torch.arange(n) + zlib.crc32(k.encode()) % 4093) % 4093
+        out[k] = (table[idx] * bounds(k, shp)).reshape(shp).contiguous()
+    return out
+
+
+def gen_checkpoint(tag, batch, size, seed):
+    """A checkpoint WRITTEN FROM THE REFERENCE MODULES' state_dict() in the format of t_est_train.py:365-373
+    ({'inference', 'discriminator', 'epoch', 'global_step'}, tensors and ints only), gzip-compressed, plus what the
+    reference modules compute from it: the per-class sweep of inference/inf_transfer_c.py:114-121, the signal-row sweep of
+    inf_transfer_e.py:136-143, the direct per-row call of inf_1year_signals.py:104, D's outputs."""
+    import gzip
+    import io
+    import math
+
+    def g_bound(k, shp):
+        if k.endswith("emb.weight"):
+            return 1.0
+        if k.endswith("weight"):
+            fan_in = int(np.prod(shp[1:]))
+            return 0.6 * (math.sqrt(2.0) if ".l1." not in k and k != "conv_last.weight" else 1.0) * math.sqrt(3.0 / fan_in)
+        return 0.1
+
+    def d_bound(k, shp):
+        if k.endswith("weight_orig"):
+            return math.sqrt(6.0 / int(np.prod(shp[1:])))
+        return 1.0 if k.endswith(("weight_u", "weight_v")) else 0.1
+
+    gp = periodic_fill(O.cunet_param_shapes(NC), seed, g_bound)
+    dp = periodic_fill(O.sndisc_param_shapes(NC), seed, d_bound)
+    for k in dp:
+        if k.endswith(("weight_u", "weight_v")):
+            dp[k] = torch.nn.functional.normalize(dp[k], dim=0, eps=1e-12)
+    G = ref_cunet.Conditional_UNet(NC)
+    G.load_state_dict(gp, strict=True)
+    D = ref_disc.SNDisc(NC)
+    D.load_state_dict(dp, strict=True)
+    epoch, step = 3, 1234
+    state = {"inference": G.state_dict(), "discriminator": D.state_dict(), "epoch": epoch, "global_step": step}   # :367-372
+    buf = io.BytesIO()
+    torch.save(state, buf)
+    name = f"ref_ckpt_e{epoch:04d}_s{step}.pt"
+    with gzip.GzipFile(os.path.join(OUT, name + ".gz"), "wb", compresslevel=9, mtime=0) as fh:
+        fh.write(buf.getvalue())
+    G.eval()
+    D.eval()
+    x, _ = O.make_inputs(batch, size, NC, seed, False)
+    onehot = torch.eye(NC)
+    rs = np.random.default_rng([78, seed])
+    signals = torch.from_numpy(rs.standard_normal((3, NC)).astype(np.float32))      # standardised signal rows (t_est_train.py:131)
+    per_row = torch.from_numpy(rs.standard_normal((batch, NC)).astype(np.float32))
+    with torch.no_grad():
+        cls = torch.stack([G(x, torch.cat([onehot[i]] * batch).view(-1, NC)) for i in range(NC)])        # inf_transfer_c.py:116-117
+        sig = torch.stack([G(x, torch.cat([signals[i]] * batch).view(-1, NC)) for i in range(len(signals))])   # inf_transfer_e.py:138-139
+        row = G(x, per_row)                                                                                   # inf_1year_signals.py:104
+        d_out = D(cls[1], torch.cat([onehot[1]] * batch).view(-1, NC))[0]
+        # the oracle on the same tensors
+        exact(cls[2], O.cunet_forward(gp, x, torch.cat([onehot[2]] * batch).view(-1, NC)), f"{tag} sweep class 2")
+        exact(row, O.cunet_forward(gp, x, per_row), f"{tag} per-row signals")
+    np.savez_compressed(os.path.join(OUT, f"ref_ckpt_{tag}.npz"), meta=np.array([batch, size, 0, seed, NC, epoch, step]),
+                        ckpt_file=np.array(name + ".gz"), class_sweep=cls.numpy(), signals=signals.numpy(), signal_sweep=sig.numpy(),
+                        per_row=per_row.numpy(), per_row_out=row.numpy(), d_out=d_out.numpy())
+    print(f"ref_ckpt_{tag}: {os.path.getsize(os.path.join(OUT, name + '.gz')) / 1024:.0f} KiB gzip of {len(buf.getvalue()) / 2**20:.1f} MiB; "
+          f"sweep abs-max {cls.abs().max():.4f}, class-to-class max diff {(cls[0] - cls[1]).abs().max():.4f}")
+
+
+def gen_eval_train_mode(tag, bs, size, seed):
+    """evaluation() the way the reference runs it (t_cls_train.py:331-352): D in TRAIN mode -- 2*B power iterations under
+    no_grad --, here with G in eval mode (its Dropout draws cannot be reproduced off the reference's RNG stream).  The loop
+    body is the reference's, executed on the REFERENCE modules; stored: the four means, D's buffers after the sweep."""
+    gp, dp = O.make_cunet_params(NC, seed), O.make_sndisc_params(NC, seed)
+    G = ref_cunet.Conditional_UNet(NC)
+    G.load_state_dict(gp, strict=True)
+    G.eval()
+    D = ref_disc.SNDisc(NC)
+    D.load_state_dict(dp, strict=True)
+    D.train()
+    images, labels = O.make_inputs(bs, size, NC, seed, True)
+    _, ref_labels = O.make_inputs(bs, size, NC, seed + 1, True)
+    lin = torch.nn.Linear(3 * 8 * 8, NC)
+    with torch.no_grad():
+        lin.weight.copy_(O._uniform("evalfix.w", (NC, 192), 0.1, seed))
+        lin.bias.copy_(O._uniform("evalfix.b", (NC,), 0.1, seed))
+    est = lambda t: lin(torch.nn.functional.adaptive_avg_pool2d(t, 8).flatten(1))      # noqa: E731  (stand-in estimator_)
+    adv, l1, w, d = [], [], [], []
+    for i in range(bs):
+        with torch.no_grad():
+            ref_expand = torch.cat([ref_labels[i]] * bs).view(-1, NC)
+            fake = G(images, ref_expand)
+            fake_c = est(fake)
+            real_d = D(images, labels)[0]
+            fake_d = D(fake, ref_expand)[0]
+        adv.append(ref_ops.gen_hinge(fake_d).item())
+        l1.append(ref_ops.l1_loss(fake, images).item())
+        w.append(ref_ops.pred_loss(fake_c, ref_expand).item())
+        d.append(ref_ops.dis_hinge(fake_d, real_d).item())
+    means = {"g_loss_adv": np.mean(adv), "g_loss_l1": np.mean(l1), "g_loss_w": np.mean(w), "d_loss": np.mean(d)}
+    om, _, ob = O.evaluation(gp, dp, est, est, images, labels, ref_labels, d_train=True)
+    for k, v in means.items():
+        assert abs(om[k] - v) <= 1e-7 * max(1.0, abs(v)), (k, om[k], v)
+    sd = D.state_dict()
+    out = {"meta": np.array([bs, size, 1, seed, NC]), "means": np.array([means[k] for k in sorted(means)]),
+           "mean_keys": np.array(sorted(means)), "est_w": lin.weight.detach().numpy(), "est_b": lin.bias.detach().numpy()}
+    for k, v in ob.items():
+        exact(sd[k], v, f"{tag} D buffer {k} after the sweep")
+        out["buf_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, f"eval_{tag}.npz"), **out)
+    print(f"eval_{tag}: {means}")
+
+
 if __name__ == "__main__":
     assert not __debug__, "run with python3 -O (reference asserts CUDA tensors, utils.py:35)"
-    gen_case("c1_b2_128_onehot", 2, 128, False, 0, True)      # BASELINE.json configs[0]
-    gen_case("b2_64_soft", 2, 64, True, 1, True)
-    gen_case("b1_32_soft", 1, 32, True, 2, True)
-    gen_case("b3_96x_onehot", 3, 96, False, 3, False)
-    gen_train_case("train_b2_64", 2, 64, 4)
-    gen_default_init_case("default_init_b2_128", 2, 128, 0)
-    gen_default_init_case("default_init_b2_64", 2, 64, 5)
-    gen_disc("b2_64", 2, 64, 0)
-    gen_disc("b3_128", 3, 128, 1)
+    cases = [
+        (gen_case, ("c1_b2_128_onehot", 2, 128, False, 0, True)),      # BASELINE.json configs[0]
+        (gen_case, ("b2_64_soft", 2, 64, True, 1, True)),
+        (gen_case, ("b1_32_soft", 1, 32, True, 2, True)),
+        (gen_case, ("b3_96x_onehot", 3, 96, False, 3, False)),
+        (gen_train_case, ("train_b2_64", 2, 64, 4)),
+        (gen_default_init_case, ("default_init_b2_128", 2, 128, 0)),
+        (gen_default_init_case, ("default_init_b2_64", 2, 64, 5)),
+        (gen_disc, ("b2_64", 2, 64, 0)),
+        (gen_disc, ("b3_128", 3, 128, 1)),
+        (gen_disc_default_init, ("default_init_b2_64", 2, 64, 7)),      # round 3
+        (gen_checkpoint, ("b2_64", 2, 64, 11)),
+        (gen_eval_train_mode, ("dtrain_b3_32", 3, 32, 8)),
+    ]
+    only = sys.argv[1:]            # e.g. `make_golden.py gen_checkpoint gen_eval` regenerates just those
+    for fn, a in cases:
+        if not only or any(o in fn.__name__ for o in only):
+            fn(*a)
     print("golden vectors written to", OUT)

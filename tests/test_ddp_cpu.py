@@ -362,3 +362,61 @@ def test_fused_node_grad_router_two_streams_world2():
     torch.mean((h2 @ P[4].t() + P[5] - y) ** 2).backward()
     for g, p in zip(g0, P):
         assert torch.allclose(torch.from_numpy(g), p.grad, atol=1e-5), (torch.from_numpy(g) - p.grad).abs().max()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# a collective moves no ``_version``: every derived-state cache (packed MFMA operands, SN identity, captured graphs, the folded
+# estimator) must be invalidated by the broadcast helpers themselves (advisor finding, round 2)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _bcast_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "weather-unet_amd"))
+    from wu.ddp import GradBucketReducer, broadcast_buffers
+    from wu import functional as WF
+    import nets
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(rank)
+        conv = nets.Conv3x3(64, 64)
+        sn = nets.SNConv3x3(64, 64)
+        code = 1
+        # what PackedConv.get() records after packing (the pack itself is a HIP launch; the key logic is host code)
+        conv._packed.key = conv._packed.make_key(conv.weight, code)
+        sn._packed.key = sn._packed.make_key(sn.weight_orig, code, sn.weight_ident())
+        v0 = (conv.weight._version, sn.weight_u._version)
+        ext0 = WF._EXTERNAL_GENERATION[0]
+        red = GradBucketReducer(list(conv.parameters()), broadcast=False)
+        fresh_before = not conv._packed.stale(conv.weight, code)
+        red.broadcast_parameters()                                       # a LATE broadcast: after the "forward" that packed
+        stale_w = conv._packed.stale(conv.weight, code)
+        sn._packed.key = sn._packed.make_key(sn.weight_orig, code, sn.weight_ident())
+        broadcast_buffers(sn)
+        stale_sn = sn._packed.stale(sn.weight_orig, code, sn.weight_ident())
+        v1 = (conv.weight._version, sn.weight_u._version)
+        q.put((rank, fresh_before, stale_w, stale_sn, v0 == v1, WF._EXTERNAL_GENERATION[0] - ext0,
+               conv.weight.detach().numpy().copy(), sn.weight_u.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_invalidates_packed_operands_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import numpy as np
+    for _, fresh_before, stale_w, stale_sn, version_unmoved, ext_bumps, _, _ in res:
+        assert fresh_before
+        assert stale_w, "broadcast_parameters() must invalidate the packed conv operands"
+        assert stale_sn, "broadcast_buffers() must invalidate the spectral-norm identity"
+        assert ext_bumps == 2
+        # the premise: if torch ever starts bumping _version on collectives this still passes; it documents why we bump
+        assert version_unmoved in (True, False)
+    assert np.array_equal(res[0][6], res[1][6]) and np.array_equal(res[0][7], res[1][7])

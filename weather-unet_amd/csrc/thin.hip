@@ -1108,7 +1108,8 @@ extern "C" int wu_conv1x1_tanh_fwd(const void* x, int ldx, const float* w, const
     const int esz = dtype == WU_BF16 ? 2 : 4;
     const int E = 16 / esz;
     const int LP = Cin / E;
-    WU_REQUIRE(Cin % E == 0 && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0, "conv1x1_tanh_fwd: Cin=%d unsupported", Cin);
+    // lanes cl = 0..2 of a pixel group each write one of the 3 output channels: a group needs at least 4 lanes (LP is a power of two)
+    WU_REQUIRE(Cin % E == 0 && LP >= 4 && LP <= 64 && (LP & (LP - 1)) == 0, "conv1x1_tanh_fwd: Cin=%d unsupported (Cin/%d must be a power of two in [4, 64])", Cin, E);
     WU_REQUIRE(((uintptr_t)x % 16) == 0 && (ldx * esz) % 16 == 0 && bias, "conv1x1_tanh_fwd: alignment/bias");
     WU_REQUIRE((long long)N * H * W < (1ll << 31), "conv1x1_tanh_fwd: N*H*W must stay below 2^31 (32-bit pixel arithmetic)");
     WU_REQUIRE((long long)H * W * ldx < (1ll << 31) && N <= 65535, "conv1x1_tanh_fwd: H*W*ldx must stay below 2^31, N below 65536");

@@ -24,8 +24,12 @@ class SNDisc(nn.Module):
         self.conv2 = sn_double_conv(64, 128)
         self.conv3 = sn_double_conv(128, 256)
         self.conv4 = sn_double_conv(256, 512)
-        # reference disc.py:16-19 applies xavier_uniform_ to the spectral-norm-DERIVED `.weight`, which does not
-        # touch `weight_orig` (a no-op for training); mirrored here on weight_orig so the init is at least used.
+        # reference disc.py:16-19 applies xavier_uniform_ to `.weight`.  At construction time that attribute is what
+        # torch.nn.utils.spectral_norm registered: `weight_orig.data` -- a plain tensor SHARING weight_orig's storage -- so
+        # the in-place init lands in weight_orig (measured against the reference: after `SNDisc(5)` every weight_orig lies
+        # within the xavier bound, not the Conv2d default's; SURVEY 8a11's "no-op" reading does not hold on this torch).
+        # Same RNG draws in the same order here: torch.manual_seed(s); SNDisc(nc) gives the reference's 40 state-dict
+        # tensors bit for bit (tests/golden/sndisc_default_init_*.npz, captured from the reference itself).
         for i in range(1, 5):
             for j in range(2):
                 nn.init.xavier_uniform_(getattr(self, 'conv{}'.format(i))[j].weight_orig, np.sqrt(2))

@@ -34,8 +34,12 @@ def l1_loss(a, b):
     one-pass kernel (loss and its gradient together); anything else is the stock torch op."""
     _same_size(a, b)
     if a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.numel() > 0:
-        from wu.functional import l1_mean
-        return l1_mean(a, b)
+        # the fused kernel reads 16-byte groups: a contiguous view at an odd storage offset (x.flatten()[1:], a row slice of an
+        # odd-width tensor) is legal input for the reference's F.l1_loss and takes the stock op here
+        ac, bc = a.contiguous(), b.contiguous()
+        if ac.data_ptr() % 16 == 0 and bc.data_ptr() % 16 == 0:
+            from wu.functional import l1_mean
+            return l1_mean(ac, bc)
     return F.l1_loss(a, b)
 
 

@@ -16,6 +16,11 @@ import torch
 import torch.distributed as dist
 
 
+def _invalidate_packed():
+    from .functional import invalidate_packed      # late: wu.functional loads the HIP library's ctypes table
+    invalidate_packed()
+
+
 def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
@@ -89,11 +94,15 @@ class GradBucketReducer:
 
     def broadcast_parameters(self, src=0):
         """Replicas start identical (weights and, for SNDisc, the power-iteration buffers via the module's
-        own broadcast_buffers call).  In place on the parameter itself under no_grad -- NOT on ``p.data``, whose writes do
-        not bump ``p._version``: the packed MFMA operand cache (wu.functional.PackedConv) keys on that version."""
+        own broadcast_buffers call).  A collective does NOT move ``p._version`` (measured: 0 -> 0 across dist.broadcast and
+        dist.all_reduce, Parameter or plain tensor), which the packed MFMA operand cache (wu.functional.PackedConv), the SN
+        identity (nets.SNConv3x3.weight_ident), captured graphs (wu.graph_infer) and the folded estimator (wu.resnet) key on:
+        the process-wide generation is bumped instead, so a broadcast AFTER a forward (re-sync, resume on rank 0 then
+        broadcast, a reducer built late) cannot leave a rank convolving with stale operands."""
         with torch.no_grad():
             for p in self.params:
                 dist.broadcast(p, src=src, group=self.group)
+        _invalidate_packed()
 
     def zero_grad(self):
         for b in self.buckets:
@@ -213,7 +222,8 @@ def broadcast_buffers(module, src=0, group=None):
         return
     with torch.no_grad():
         for b in module.buffers():
-            dist.broadcast(b, src=src, group=group)     # on the buffer itself: bumps its version (PackedConv identity)
+            dist.broadcast(b, src=src, group=group)
+    _invalidate_packed()     # collectives do not move ``_version``: bump the generation every derived-state cache keys on
 
 
 def shard_batch(batch, rank, world):

@@ -32,15 +32,21 @@ def _grad_nhwc(g, code):
 # batched into one by ``repack_stale``).  Updates made outside ``torch.optim`` with ops that skip the version counter must call
 # ``invalidate_packed()``.
 _WEIGHT_GENERATION = [0]
+# bumped by explicit invalidate_packed() calls only (collective broadcasts, raw-pointer writes): what a FROZEN module's derived
+# state (the estimator's folded BatchNorm, wu.resnet) keys on, so that optimizer steps of OTHER networks do not rebuild it
+_EXTERNAL_GENERATION = [0]
 
 
 def invalidate_packed():
-    """Force every PackedConv to rebuild on its next use (weights were changed behind autograd's version counter)."""
+    """Force every PackedConv / captured graph / folded estimator state to rebuild on its next use: weights were changed behind
+    autograd's version counter (``dist.broadcast`` / ``dist.all_reduce`` on a parameter do NOT move ``_version`` -- measured on
+    torch 2.10, gloo and nccl alike --, nor do raw-pointer writes)."""
     _WEIGHT_GENERATION[0] += 1
+    _EXTERNAL_GENERATION[0] += 1
 
 
 def _on_optimizer_step(optimizer, args, kwargs):
-    invalidate_packed()
+    _WEIGHT_GENERATION[0] += 1
 
 
 from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402

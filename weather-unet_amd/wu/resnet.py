@@ -151,8 +151,10 @@ class ResNet101Estimator(nn.Module):
         ts = list(self.parameters()) + list(self.buffers())
         # a TRAINABLE estimator may be updated by a fused optimizer, which does not move ``_version`` (wu.functional): then the
         # optimizer-step generation joins the key; the frozen estimator of the GAN loop keeps its plan across G / D steps
-        from .functional import _WEIGHT_GENERATION
-        gen = _WEIGHT_GENERATION[0] if any(p.requires_grad for p in self.parameters()) else 0
+        # (explicit invalidate_packed() calls -- a collective broadcast moves no ``_version`` either -- reach both through
+        # the external generation)
+        from .functional import _EXTERNAL_GENERATION, _WEIGHT_GENERATION
+        gen = _WEIGHT_GENERATION[0] if any(p.requires_grad for p in self.parameters()) else _EXTERNAL_GENERATION[0]
         return (self.precision, gen) + tuple((t.data_ptr(), t._version) for t in ts)
 
     def plan(self):

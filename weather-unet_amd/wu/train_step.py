@@ -18,7 +18,8 @@ Differences from the reference loop, all numerically neutral:
     ``rand_images`` (:424) and then twice on the same ``images`` (:297 in update_discriminator, :237 in update_inference), three
     no-grad forwards of a deterministic function of which two are identical; the one call on the concatenated batch returns the
     same numbers (no cross-sample coupling in eval-mode BatchNorm) with half the launches and twice the GEMM rows;
-  * evaluation() runs its B transfers as ONE (B*B)-image pass of G / D / estimator instead of B passes (SURVEY.md 8f.4);
+  * evaluation() runs its B transfers as ONE (B*B)-image pass of G / estimator instead of B passes; D joins
+    the batched pass in eval mode and runs per pass in train mode (one power iteration per forward, as in the reference);
   * data parallel (new): G and D gradients are averaged by two ``GradBucketReducer``s; the D
     gradients that g_loss.backward() deposits (and the next d_opt.zero_grad() discards, t_cls_train.py:291) are
     not all-reduced.
@@ -180,16 +181,25 @@ class WeatherTransferStep:
     @torch.no_grad()
     def evaluation(self, images, labels, ref_labels, max_images=1024):
         """The test-time sweep: every image of the batch transferred to every reference row's conditioning, averaged losses.
-        The reference runs B passes of G / estimator / D over the B-image batch; this is ONE pass over the B*B (image,
-        condition) pairs (chunked to ``max_images`` images), D(images, labels) computed once -- identical means, since every
-        per-pass loss is a mean over equally sized blocks.  G / D stay in whatever train / eval mode they are in (the
-        reference never calls .eval(): Dropout and the power iteration are active there).
+        The reference runs B passes of G / estimator / D over the B-image batch; here G and the estimator run ONE pass over
+        the B*B (image, condition) pairs (chunked to ``max_images`` images).  G / D stay in whatever train / eval mode they
+        are in (the reference never calls .eval(): Dropout and the power iteration are active there), and D follows its mode:
+
+        * D in EVAL mode: D(images, labels) once and D on all fakes in the batched pass -- identical means, since every
+          per-pass loss is a mean over equally sized blocks;
+        * D in TRAIN mode (the reference's actual mode, t_cls_train.py:331-341): each of the reference's 2*B discriminator
+          forwards runs one power iteration, so every pass sees its own W/sigma and D's ``weight_u`` / ``weight_v`` -- training
+          state -- have moved 2*B iterations when the sweep returns.  That is reproduced exactly: D runs per pass, real batch
+          then fake batch, in the reference's order (2*B forwards of B images: the same FLOPs as the batched form, more
+          launches; G and the estimator, 95 % of the work, stay batched).
+
         Returns (dict of device scalars g_loss_adv, g_loss_l1, g_loss_w, d_loss; fake images (B, B, 3, H, W): [i] = transfers
         to ref_labels[i])."""
         bs, nc = images.shape[0], ref_labels.shape[1]
         if labels.dim() == 1:                                                            # :327-329 (--one_hot)
             labels = torch.eye(nc, device=images.device)[labels]
-        real_d = self.discriminator(images, labels)[0]                                   # :340
+        d_train = self.discriminator.training
+        real_d = None if d_train else self.discriminator(images, labels)[0]              # :340
         est = self.estimator_ if self.mode == "cls" else self.estimator                  # :338 / t_est_train.py:309
         rows = max(1, max_images // bs)
         fakes, fake_d, fake_c = [], [], []
@@ -200,14 +210,25 @@ class WeatherTransferStep:
             f = self.inference(x, cond)                                                  # :337
             fakes.append(f)
             fake_c.append(est(f))                                                        # :338
-            fake_d.append(self.discriminator(f, cond)[0])                                # :341
+            if not d_train:
+                fake_d.append(self.discriminator(f, cond)[0])                            # :341
         fake = torch.cat(fakes)
         cond_all = ref_labels.repeat_interleave(bs, dim=0)
+        if d_train:
+            d_terms = []
+            for i in range(bs):                                                          # the reference's order, pass by pass
+                real_i = self.discriminator(images, labels)[0]                           # :340 power iteration 2i+1
+                fd_i = self.discriminator(fake[i * bs:(i + 1) * bs], cond_all[i * bs:(i + 1) * bs])[0]   # :341 iteration 2i+2
+                fake_d.append(fd_i)
+                d_terms.append(ops.dis_hinge(fd_i, real_i))                              # :352
+            d_loss = torch.stack(d_terms).mean()
         fd = torch.cat(fake_d)
+        if not d_train:
+            d_loss = ops.dis_hinge(fd, real_d)                                           # :352
         losses = {
             "g_loss_adv": ops.gen_hinge(fd),                                             # :349
             "g_loss_l1": ops.l1_loss(fake, images.repeat(bs, 1, 1, 1)),                  # :350
             "g_loss_w": ops.pred_loss(torch.cat(fake_c), cond_all),                      # :351
-            "d_loss": ops.dis_hinge(fd, real_d),                                         # :352
+            "d_loss": d_loss,
         }
         return losses, fake.view(bs, bs, *images.shape[1:])
