@@ -280,25 +280,45 @@ def spectral_normalize(w_orig, u, v, train=True, eps=1e-12):
     return w_orig / sigma, u, v
 
 
-def sn_double_conv(p, name, x, train, new_buffers):
-    """nets.py:26-33: SN(Conv3x3 cin->cin s1 p1) -> SN(Conv3x3 cin->cout s2 p1) -> LeakyReLU(0.2);
-    no activation between the two convs."""
+def _q_value(t, emu):
+    """(emu) a tensor the kernels READ as bf16 but whose gradient they keep in fp32 (straight-through rounding)."""
+    return t + (t.to(torch.bfloat16).float() - t).detach() if emu else t
+
+
+def sn_double_conv(p, name, x, train, new_buffers, emu=False):
+    """nets.py:26-33: SN(Conv3x3 cin->cin s1 p1) -> SN(Conv3x3 cin->cout **s2** p1) -> LeakyReLU(0.2);
+    no activation between the two convs.
+
+    ``emu`` (bf16-emulation, NOT part of the reference's arithmetic -- see cunet_forward): the storage points of the HIP bf16
+    path.  The 3->3 conv of conv1 stays fp32 end to end (image layout, NCHW fp32 in and out); the 3->64 stride-2 conv reads that
+    fp32 tensor and W/sigma as bf16 MFMA operands; every 64+-channel conv has bf16 operands, fp32 accumulate + bias
+    (+ LeakyReLU), bf16 store.  Backward: the gradient of every bf16 tensor is parked in bf16, and the LeakyReLU-gated gradient
+    is a second bf16 tensor (the kernels gate dY once, up front, and both gradient GEMMs read that)."""
+    first = p[f"{name}.0.weight_orig"].shape[1] == 3
+    gq = _RoundGradBF16.apply if emu else (lambda t: t)
     for j, stride in ((0, 1), (1, 2)):
         k = f"{name}.{j}"
         w, u, v = spectral_normalize(p[k + ".weight_orig"], p[k + ".weight_u"], p[k + ".weight_v"], train)
         new_buffers[k + ".weight_u"], new_buffers[k + ".weight_v"] = u, v
-        x = F.conv2d(x, w, p[k + ".bias"], stride=stride, padding=1)
-    return F.leaky_relu(x, 0.2)
+        if first and j == 0:
+            x = F.conv2d(x, w, p[k + ".bias"], stride=stride, padding=1)                # fp32 kernel, fp32 NCHW output
+            continue
+        xin = _q_value(x, emu) if first else x
+        z = F.conv2d(xin, _qw(w, emu), p[k + ".bias"], stride=stride, padding=1)
+        x = _q(z, emu) if j == 0 else z
+    return _q(F.leaky_relu(gq(x), 0.2), emu)
 
 
-def sndisc_forward(p, x, c, train=True):
+def sndisc_forward(p, x, c, train=True, emulate_bf16=False):
     """SNDisc.forward (disc.py:27-38).  Returns ([out, c1, c2, c3, c4], new_buffers) where
-    new_buffers holds the power-iteration-updated weight_u / weight_v of the 10 SN layers."""
+    new_buffers holds the power-iteration-updated weight_u / weight_v of the 10 SN layers.
+    ``emulate_bf16``: see sn_double_conv (the pooled features and both linear heads stay fp32, as in the HIP path)."""
     nb = {}
-    c1 = sn_double_conv(p, "conv1", x, train, nb)            # :28
-    c2 = sn_double_conv(p, "conv2", c1, train, nb)           # :29
-    c3 = sn_double_conv(p, "conv3", c2, train, nb)           # :30
-    c4 = sn_double_conv(p, "conv4", c3, train, nb)           # :31
+    emu = emulate_bf16
+    c1 = sn_double_conv(p, "conv1", x, train, nb, emu)       # :28
+    c2 = sn_double_conv(p, "conv2", c1, train, nb, emu)      # :29
+    c3 = sn_double_conv(p, "conv3", c2, train, nb, emu)      # :30
+    c4 = sn_double_conv(p, "conv4", c3, train, nb, emu)      # :31
     feat = torch.sum(c4, [2, 3])                             # :32 global sum pool
     w, u, v = spectral_normalize(p["l.weight_orig"], p["l.weight_u"], p["l.weight_v"], train)
     nb["l.weight_u"], nb["l.weight_v"] = u, v

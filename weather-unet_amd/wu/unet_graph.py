@@ -130,6 +130,10 @@ class GradRouter:
             self.sink.grad_written(self.SP[iw + 1])
 
 
+# tracing: set to a dict and the next fused backward leaves its stage inputs and every intermediate gradient tensor in it (the node
+# is ONE autograd function, so autograd hooks cannot see inside); None = off (no cost, no references kept)
+CAPTURE = None
+
 BLOCKS = ("dconv_down1", "dconv_down2", "dconv_down3", "dconv_down4", "dconv_up3", "dconv_up2", "dconv_up1")
 
 
@@ -315,6 +319,12 @@ class UNetFn(Function):
         if side is not None:
             main.wait_stream(side)
             keep.clear()
+        if CAPTURE is not None:
+            # tracing hook (tests/test_gpu_round3.py: stage-by-stage gradient checks with the upstream gradient held fixed)
+            CAPTURE.update(x=x, cat1=cat1, cat2=cat2, cat3=cat3, p1=p1, p2=p2, p3=p3, b4=b4, u3b=u3b, u2b=u2b, u1b=u1b, out=out,
+                           gout=gout, g_u1b=g_u1b, g_cat1=g_cat1, g_u2b=g_u2b, g_cat2=g_cat2, g_u3b=g_u3b, g_cat3=g_cat3, g_b4=g_b4,
+                           g_p3=g_p3, g_conv3=g_conv3, g_p2=g_p2, g_conv2=g_conv2, g_p1=g_p1, g_conv1=g_conv1,
+                           d_style=(dys3, dym3, dys2, dym2, dys1, dym1))
         flat = []
         for name in BLOCKS:
             for j in (0, 2):
