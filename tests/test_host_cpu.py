@@ -165,3 +165,41 @@ def test_packed_weight_cache_follows_optimizer_steps():
     with torch.no_grad():
         w.add_(1.0)
     assert pc.stale(w, 1)
+
+
+def test_bf16_sum_order_witness():
+    """The checked basis of the bf16 gradient tolerances (DESIGN 2; tests/test_gpu_round2.py::test_bf16_gradients_vs_emulating_oracle
+    accepts the HIP gradient within 2x the emulation-to-emulation distance).  Two CPU runs of the SAME bf16-emulating graph that
+    differ only in the order their convs visit the input channels (``sum_order``: the same real-number function, another fp32
+    rounding sequence):
+      * in fp32 the re-ordering is invisible (every gradient cos >= 0.9999999);
+      * in the bf16 emulation it is not -- the layers downstream of the last AdaIN (dconv_up1.*, conv_last.*, adain1.l1.*) still
+        agree to >= 0.999, every gradient upstream of an instance-norm backward only to 0.95-0.996 (measured B=2 64x64: up3.2.bias
+        0.951, the encoder 0.975-0.995).
+    So an end-to-end bf16 gradient cosine of 0.95-0.98 on the deep layers is the precision mode, not a kernel property -- which
+    is why the kernels' own arithmetic is pinned stage by stage with the upstream gradient held fixed (test_gpu_round3.py)."""
+    nc, seed, n, size = 5, 13, 2, 64
+    r = O._rng("emu", seed)
+    x = torch.from_numpy(r.uniform(-1, 1, size=(n, 3, size, size)).astype(np.float32))
+    c = torch.softmax(torch.from_numpy(r.standard_normal((n, nc)).astype(np.float32)), 1)
+    grads = {}
+    for tag, emu, order in (("emu", True, None), ("emu2", True, 1), ("fp32", False, None), ("fp32b", False, 1)):
+        p = {k: v.clone().requires_grad_(True) for k, v in O.make_cunet_params(nc, seed).items()}
+        O.bench_loss(O.cunet_forward(p, x, c, None, emulate_bf16=emu, sum_order=order), x).backward()
+        grads[tag] = {k: v.grad for k, v in p.items() if v.grad is not None}
+
+    def cos(a, b):
+        a, b = a.double().reshape(-1), b.double().reshape(-1)
+        return (torch.dot(a, b) / (a.norm() * b.norm())).item()
+
+    assert len(grads["emu"]) == 36
+    deep = []
+    for k in grads["emu"]:
+        assert cos(grads["fp32"][k], grads["fp32b"][k]) >= 0.9999999, k
+        ee = cos(grads["emu"][k], grads["emu2"][k])
+        if k.startswith(("dconv_up1", "conv_last", "adain1")):
+            assert ee >= 0.999, (k, ee)
+        else:
+            assert 0.9 <= ee, (k, ee)
+            deep.append(ee)
+    assert len(deep) == 28 and min(deep) <= 0.98 and max(deep) <= 0.9975      # the amplification is there, on every deep layer
