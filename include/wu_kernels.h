@@ -43,16 +43,24 @@ const char* wu_last_error(void);
 int wu_version(void);
 /* Compute units of the current HIP device (256 on MI355X): the persistent conv / weight-gradient grids are sized from it. */
 int wu_cu_count(void);
-/* Kernel-variant switches for in-process A/B benchmarking.  Defaults = production choices; results are identical either way.
+/* Kernel-variant switches for in-process A/B benchmarking -- DIAGNOSTIC / TEST-ONLY: process-global mutable state, not part of
+ * the re-entrant launcher contract.  A production caller never touches it: the defaults ARE the production
+ * choices and every variant computes identical results; set it only from a single-threaded benchmark harness, between launches.
  *   0: conv LDS-DMA path (0 off = generic template, 1 auto wave shape (default), 2 always 4 waves, 3 always 8 waves)
  *   1: persistent tile loop on/off      2: LDS-DMA wgrad (0 off, 1 = 8 waves (default), 2 = 4 waves)      3: unused
  *   4: wgrad DMA issue spread over K-steps (default 1)   5: first conv (0 matrix cores in bf16 (default), 1 rows kernel, 2 VALU kernel)
- *   6: static priority for the younger wave half (default 1)   7: grid-strided tile assignment (default 1) */
+ *   6: static priority for the younger wave half (default 1)   7: grid-strided tile assignment (default 1)
+ *   8 / 9: marching AdaIN-upsample backward / forward (default 1)
+ *   10: persistent-grid size override in compute units (0 = the device's count; experiments on CU-masked streams) */
 int wu_set_option(int key, int value);
 /* Diagnostic: device buffer of 256*8*8 uint64 receiving per-wave phase cycle sums of the persistent conv / wgrad kernels
  * (DMA wait, compute, whole-kernel s_memtime and s_memrealtime deltas -> in-kernel clock, barrier, epilogue, tiles, chunks);
  * NULL (default) disables stamping. */
 int wu_set_debug_buffer(void* p);
+/* Experiment support (DIAGNOSTIC): a HIP stream confined to the compute units whose bits are set in mask[0..words) (hipExtStreamCreateWithCUMask),
+ * for measuring CU-partitioned overlap of the data-gradient and weight-gradient kernels (scratch/ab_cumask.py); unused by the product path. */
+int wu_stream_create_cu_mask(const unsigned* mask, int words, void** stream_out);
+int wu_stream_destroy(void* stream);
 
 /* ---- weights -------------------------------------------------------------------------------
  * Repack one 3x3 conv weight (nets.py:20,22,28-31; OIHW fp32, the state-dict layout) into the two

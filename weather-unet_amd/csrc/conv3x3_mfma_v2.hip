@@ -264,12 +264,21 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         // One K chunk.  Chunk 0 is a separate instance of this code (FIRST): only it issues the previous tile's deferred stores, and
         // it is never the last chunk (Cin >= 64) -- so `ov` is dead before the loop over the later chunks, where the bias / gate
         // registers come alive (inside one loop the allocator has to keep all three sets at once: 47 spilled registers).
-        auto do_chunk = [&](const int c, auto first_tag) __attribute__((always_inline)) {
+        // Fragment ring (three register sets at 8 waves, two at 4), at TILE scope: the MFMAs of a chunk's last step(s) are carried
+        // across the chunk-top barrier (round 3).  Their fragments are in registers before the barrier (the LDS buffer can be handed
+        // to the DMA), and they execute BEHIND the first fragment reads of the next chunk -- the pipeline no longer drains at the
+        // end of every chunk and refills (one LDS round trip with the matrix pipe idle, for both waves of a SIMD at once) behind
+        // every barrier.  Same MFMA order per accumulator: results are bit-identical.  Only a tile's last chunk runs all 18 steps.
+        constexpr int RING = NW == 8 ? 3 : 2, CARRY = NW == 8 ? 2 : 1;     // steps carried: 16, 17 / 17
+        uint4 raf[RING][Q::RPW], rbf[RING][2];
+        auto do_chunk = [&](const int c, auto first_tag, auto last_tag) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value;      // the tile's last chunk: nothing is carried out of it
+            static_assert(!(FIRST && LAST), "a tile has at least two chunks (Cin >= 64)");
             const char* lds = smem + buf * K::BUF;
             const int nxt = buf ^ 1;
             // what to fetch while computing this chunk: the next chunk of this tile, or chunk 0 of the next tile
-            const bool last = !FIRST && c + 1 == nchunks;
+            constexpr bool last = LAST;
             const bool more = !last || tile + t_step < t_end;
             const int c1 = last ? 0 : (c + 1) * 32;
             // this wave's pieces of the current chunk must have landed.  Right after an interior tile's epilogue the 8
@@ -328,9 +337,28 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
             if constexpr (NW == 8) {
                 // fragments TWO steps ahead (ring of three register sets): whichever wave of a SIMD loses the arbitration runs
                 // the tail of the chunk alone, and a lone wave's 4 MFMAs per step (128 cycles) do not cover an LDS round trip
-                uint4 af[3][Q::RPW], bf[3][2];
-                load_step(0, af[0], bf[0]);
-                load_step(1, af[1], bf[1]);
+                auto (&af) = raf;
+                auto (&bf) = rbf;
+                auto mma_step = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int mi = 0; mi < Q::RPW; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) mma(acc[mi][ni], bf[slot][ni], af[slot][mi]);   // D^T = W * X^T
+                };
+                if constexpr (FIRST) {
+                    load_step(0, af[0], bf[0]);
+                    load_step(1, af[1], bf[1]);
+                } else {
+                    // carried in: steps 16 / 17 of the previous chunk sit in ring slots 1 / 2 (16 % 3, 17 % 3); slot 0 is free
+                    load_step(0, af[0], bf[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_step(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_step(1, af[1], bf[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_step(2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int step = 0; step < 18; ++step) {
                     if (step + 2 < 18) load_step(step + 2, af[(step + 2) % 3], bf[(step + 2) % 3]);
@@ -348,14 +376,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                     // pin the order: left alone, the scheduler sinks the fragment reads of the DMA-free steps (6..17) to just
                     // before their first use and waits lgkmcnt(0) in front of every MFMA
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int mi = 0; mi < Q::RPW; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) mma(acc[mi][ni], bf[step % 3][ni], af[step % 3][mi]);   // D^T = W * X^T
+                    if (LAST || step < 18 - CARRY) mma_step(step % 3);          // steps 16, 17: carried into the next chunk
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
-                uint4 af[2][Q::RPW], bf[2][2];
+                auto (&af) = raf;
+                auto (&bf) = rbf;
                 // ONE wave per SIMD: nothing else fills the matrix pipe while this wave issues loads, so the stream is pinned
                 // instruction by instruction: after MFMA m of step s comes fragment read m of step s+1 (6 reads over the
                 // first 6 of 8 MFMAs), the DMA pieces ride behind the last MFMA; the whole chunk is one basic block.
@@ -370,14 +396,24 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                     }
                 };
                 const unsigned kill = more ? 0u : kWuOOB;
+                if constexpr (FIRST) {
 #pragma unroll
-                for (int f = 0; f < NF; ++f) load_frag(0, f, af[0], bf[0]);
+                    for (int f = 0; f < NF; ++f) load_frag(0, f, af[0], bf[0]);
+                } else {
+                    // carried in: step 17 of the previous chunk (ring slot 1); its MFMAs cover the fragment reads of step 0
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        mma(acc[m >> 1][m & 1], bf[1][m & 1], af[1][m >> 1]);
+                        if (m < NF) load_frag(0, m, af[0], bf[0]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
 #pragma unroll
                 for (int step = 0; step < 18; ++step) {
                     const int cur = step & 1;
 #pragma unroll
                     for (int m = 0; m < NM; ++m) {
-                        mma(acc[m >> 1][m & 1], bf[cur][m & 1], af[cur][m >> 1]);
+                        if (LAST || step < 18 - CARRY) mma(acc[m >> 1][m & 1], bf[cur][m & 1], af[cur][m >> 1]);   // step 17: carried
                         if (step + 1 < 18 && m < NF) load_frag(step + 1, m, af[cur ^ 1], bf[cur ^ 1]);
                         // 20 pieces, two behind the last MFMA of steps 0..9 (four per step over steps 0..4 measured slower)
                         if (m == NM - 1 && 2 * step < Q::NP) {
@@ -399,8 +435,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
             if (FIRST && ov_pending) { stores_in_flight = ov_interior; bits_in_flight = ovb_pending; ov_pending = false; ovb_pending = false; }
             if (FIRST) WU_STAMP(t_comp); else WU_STAMP(t_comp_rest);
         };
-        do_chunk(0, std::true_type{});
-        for (int c = 1; c < nchunks; ++c) do_chunk(c, std::false_type{});
+        do_chunk(0, std::true_type{}, std::false_type{});
+        for (int c = 1; c + 1 < nchunks; ++c) do_chunk(c, std::false_type{}, std::false_type{});
+        do_chunk(nchunks - 1, std::false_type{}, std::true_type{});
 
         // ---- epilogue of this tile (its last chunk sat in buffer buf^1, now free; buffer `buf` is receiving the next
         //      tile's chunk 0): bias + activation in fp32, packed to bf16 in registers (`ov`); the stores follow later ----

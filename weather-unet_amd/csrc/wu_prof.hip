@@ -11,6 +11,7 @@ extern "C" int wu_version(void) { return 2; }
 // Compute units of the current device, read once (the persistent conv / weight-gradient grids launch one workgroup per CU).
 // Without a usable device (the CPU-only build container: workspace sizing in the ABI tests) the MI355X figure is assumed.
 int wu_num_cus() {
+    if (g_wu_opt[WU_OPT_GRID_CUS] > 0) return g_wu_opt[WU_OPT_GRID_CUS];   // experiment: persistent grids sized for a CU-masked stream
     static int cus = 0;
     if (cus == 0) {
         int dev = 0, n = 0;
@@ -20,6 +21,19 @@ int wu_num_cus() {
     return cus;
 }
 extern "C" int wu_cu_count(void) { return wu_num_cus(); }
+
+// Experiment support (scratch/ab_cumask.py): a stream confined to the compute units whose bits are set in `mask` (`words` x 32 bits).
+extern "C" int wu_stream_create_cu_mask(const unsigned* mask, int words, void** stream_out) {
+    WU_REQUIRE(mask && words > 0 && stream_out, "stream_create_cu_mask: bad args");
+    hipStream_t s = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+    if (e != hipSuccess) WU_FAIL((int)e, "hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+    *stream_out = (void*)s;
+    return 0;
+}
+extern "C" int wu_stream_destroy(void* stream) {
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : -1;
+}
 
 // tuning switches (A/B benchmarking of kernel variants inside one process; defaults are the production choices)
 int g_wu_opt[16] = {/*CONV_V2*/ 1, /*CONV_PERSISTENT*/ 1, /*WGRAD_V2*/ 1, /*CONV_CT_SLOWEST*/ 0, /*WGRAD_DMA_INTERLEAVE*/ 1, /*C3_ROWS*/ 0, /*CONV_PRIO*/ 1, /*CONV_STRIDED*/ 1, /*ADAIN_BWD_MARCH*/ 1, /*ADAIN_FWD_MARCH*/ 1, 0, 0, 0, 0, 0, 0};

@@ -29,6 +29,8 @@ SIGNATURES = {
     "wu_cu_count": (I, []),
     "wu_set_option": (I, [I, I]),
     "wu_set_debug_buffer": (I, [P]),
+    "wu_stream_create_cu_mask": (I, [P, I, P]),
+    "wu_stream_destroy": (I, [P]),
     "wu_spectral_norm_scratch_floats": (SZ, [I, I]),
     "wu_spectral_norm_fwd": (I, [P, I, I, P, P, I, F, P, P, P, P]),
     "wu_spectral_norm_bwd": (I, [P, P, P, P, P, P, I, I, P, P]),
