@@ -51,7 +51,8 @@ int wu_cu_count(void);
  *   4: wgrad DMA issue spread over K-steps (default 1)   5: first conv (0 matrix cores in bf16 (default), 1 rows kernel, 2 VALU kernel)
  *   6: static priority for the younger wave half (default 1)   7: grid-strided tile assignment (default 1)
  *   8 / 9: marching AdaIN-upsample backward / forward (default 1)
- *   10: persistent-grid size override in compute units (0 = the device's count; experiments on CU-masked streams) */
+ *   10: persistent-grid size override in compute units (0 = the device's count; experiments on CU-masked streams)
+ *   11: Cin = 64 / one-cout-tile convs keep both weight chunks resident in LDS across a workgroup's tiles (default 1) */
 int wu_set_option(int key, int value);
 /* Diagnostic: device buffer of 256*8*8 uint64 receiving per-wave phase cycle sums of the persistent conv / wgrad kernels
  * (DMA wait, compute, whole-kernel s_memtime and s_memrealtime deltas -> in-kernel clock, barrier, epilogue, tiles, chunks);

@@ -50,6 +50,7 @@ struct V2Args {
     int ldx, ldy, ldegate, egate_act, ldpool;
     int N, H, W, Cin, Cout, act;
     int tiles_x, tiles_y, cout_tiles, ntiles, prio_mode, strided;
+    int w_resident;              // Cin == 64 and ONE cout tile: both weight chunks stay in LDS for the life of the workgroup
     unsigned long long* dbg;     // diagnostic: per-workgroup phase cycle sums (NULL in production)
 };
 
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
             const int nxt = buf ^ 1;
             // what to fetch while computing this chunk: the next chunk of this tile, or chunk 0 of the next tile
             constexpr bool last = LAST;
+            const bool need_w = !a.w_resident || (FIRST && tile == t_begin);     // (wave-uniform)
             const bool more = !last || tile + t_step < t_end;
             const int c1 = last ? 0 : (c + 1) * 32;
             // this wave's pieces of the current chunk must have landed.  Right after an interior tile's epilogue the 8
@@ -364,9 +366,13 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                     if (step + 2 < 18) load_step(step + 2, af[(step + 2) % 3], bf[(step + 2) % 3]);
                     // issue the next chunk's 10 DMA pieces at the START of this chunk (2 per step): they get ~3/4 of the chunk to
                     // land (LDS-DMA latency ~1.2 us)
+                    // (resident weights: with two chunks per tile, chunk q always sits in buffer q, and with one cout tile every tile
+                    //  multiplies by the same slab -- after the workgroup's first tile only the halo pieces are fetched: -4...-8 %.
+                    //  The mirror image -- a pixel tile's halo chunks kept for its several cout tiles (64 -> 128 / 192 layers, contiguous
+                    //  tile walk) -- measured 2-2.6 % SLOWER than the grid-strided walk that re-fetches them from L2: not built.)
                     if (more && 2 * step < Q::NP) {
-                        issue_piece(2 * step, c1, nxt);
-                        if (2 * step + 1 < Q::NP) issue_piece(2 * step + 1, c1, nxt);
+                        if (need_w || 2 * step < Q::NH) issue_piece(2 * step, c1, nxt);
+                        if (2 * step + 1 < Q::NP && (need_w || 2 * step + 1 < Q::NH)) issue_piece(2 * step + 1, c1, nxt);
                     }
                     // the previous tile's outputs, one store per step once this chunk's DMA pieces are out (they stay the
                     // youngest vector-memory ops: the next chunk-top wait is vmcnt(NST))
@@ -607,6 +613,7 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     a.dbg = (unsigned long long*)g_wu_dbg_ptr;
     a.prio_mode = g_wu_opt[WU_OPT_CONV_PRIO];
     a.strided = g_wu_opt[WU_OPT_CONV_STRIDED];
+    a.w_resident = 0;
     const long long ntiles = (long long)N * a.tiles_x * a.tiles_y * a.cout_tiles;
     if (ntiles >= (1ll << 31)) return -1;
     a.ntiles = (int)ntiles;
@@ -629,6 +636,7 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     a.gbits = (gated == 0 && act == WU_ACT_RELU && !pool) ? (unsigned*)gate_bits_out : nullptr;
     if (a.gbits) gated = 3;
     const bool nw4 = mode == 2 || (mode == 1 && Cin >= 256);
+    a.w_resident = (!nw4 && Cin == 64 && a.cout_tiles == 1 && g_wu_opt[WU_OPT_CONV_W_RESIDENT]) ? 1 : 0;
 #define WU_V2_GO(NW_, G_) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<NW_, G_>), dim3((int)grid), dim3(NW_ * 64), 2 * K::BUF, s, a)
     if (nw4) { if (gated == 3) WU_V2_GO(4, 3); else if (gated == 2) WU_V2_GO(4, 2); else if (gated == 1) WU_V2_GO(4, 1); else WU_V2_GO(4, 0); }
     else { if (gated == 3) WU_V2_GO(8, 3); else if (gated == 2) WU_V2_GO(8, 2); else if (gated == 1) WU_V2_GO(8, 1); else WU_V2_GO(8, 0); }
