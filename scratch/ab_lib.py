@@ -29,6 +29,9 @@ def load_old():
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 7
     new, old = _lib.load(), load_old()
+    for kv in sys.argv[2:]:                  # options for the NEW library only, e.g. 0=2 (always the 4-wave conv shape)
+        k, v = kv.split("=")
+        new.wu_set_option(int(k), int(v))
     dev, bf, B, S = torch.device("cuda:0"), torch.bfloat16, 32, 256
     sp = torch.cuda.current_stream().cuda_stream
 

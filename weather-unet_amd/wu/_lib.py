@@ -97,9 +97,15 @@ def load():
         # loader binds this library to the HIP runtime instance torch initialises -- two runtime copies in
         # one process do not share devices, streams or allocations.
         import torch  # noqa: F401
-        _check_not_stale()
-        lib = ctypes.CDLL(LIB_PATH)
+        # WU_AB_LIB: benchmark harness only (scratch/): run the whole product path on ANOTHER build of the library (a baseline
+        # revision, scratch/build_baseline_lib.sh) for same-box A/B timing of the full step; entry points that build lacks stay unbound
+        ab = os.environ.get("WU_AB_LIB")
+        if not ab:
+            _check_not_stale()
+        lib = ctypes.CDLL(ab or LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if ab and not hasattr(lib, name):
+                continue
             fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
