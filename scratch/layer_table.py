@@ -25,7 +25,9 @@ def main():
     dev = torch.device("cuda:0")
     bf = torch.bfloat16
 
-    def run(fn, reps=7):
+    def run(fn, reps=7, inner=4):
+        """Median over `reps` of (time of `inner` back-to-back launches) / inner: a single launch between two events carries the
+        host's launch latency (10-20 us on an idle stream), which back-to-back launches hide behind the running kernel."""
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
@@ -33,34 +35,44 @@ def main():
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            fn()
+            for _ in range(inner):
+                fn()
             e1.record()
             torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1) * 1e3)
+            ts.append(e0.elapsed_time(e1) * 1e3 / inner)
         return statistics.median(ts)
 
     def act(c, s):
         return (torch.rand((B, s, s, c), device=dev) * 2 - 1).to(bf).permute(0, 3, 1, 2)
 
     rows_conv, rows_glue = [], []
-    layers = [("down1.2", 64, 64, S, True), ("down2.0", 64, 128, S // 2, False), ("down2.2", 128, 128, S // 2, True),
-              ("down3.0", 128, 256, S // 4, False), ("down3.2", 256, 256, S // 4, True), ("down4.0", 256, 512, S // 8, False),
-              ("down4.2", 512, 512, S // 8, False), ("up3.0", 768, 256, S // 4, False), ("up3.2", 256, 256, S // 4, False),
-              ("up2.0", 384, 128, S // 2, False), ("up2.2", 128, 128, S // 2, False), ("up1.0", 192, 64, S, False), ("up1.2", 64, 64, S, False)]
+    # the variants the fused graph launches (wu/unet_graph.py): a block's FIRST conv writes the gate bits of its output and its data
+    # gradient is ungated; the SECOND conv is plain (or + fused 2x2 max-pool on the encoder) and its data gradient reads the gate bits
+    layers = [("down1.2", 64, 64, S, "pool"), ("down2.0", 64, 128, S // 2, "bits"), ("down2.2", 128, 128, S // 2, "pool"),
+              ("down3.0", 128, 256, S // 4, "bits"), ("down3.2", 256, 256, S // 4, "pool"), ("down4.0", 256, 512, S // 8, "bits"),
+              ("down4.2", 512, 512, S // 8, "plain"), ("up3.0", 768, 256, S // 4, "bits"), ("up3.2", 256, 256, S // 4, "plain"),
+              ("up2.0", 384, 128, S // 2, "bits"), ("up2.2", 128, 128, S // 2, "plain"), ("up1.0", 192, 64, S, "bits"), ("up1.2", 64, 64, S, "plain")]
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
-    for name, ci, co, s, pool in layers:
+    for name, ci, co, s, kind in layers:
         x, gy = act(ci, s), act(co, s)
         w = (torch.rand((co, ci, 3, 3), device=dev) * 2 - 1) * 0.05
         wf, wd = K.pack_conv3x3(w, 1)
         bias = torch.zeros(co, device=dev)
         y, dx = empty_nhwc(B, co, s, s, bf, dev), empty_nhwc(B, ci, s, s, bf, dev)
         fl = 2.0 * B * s * s * 9 * ci * co
-        if pool:
+        if kind == "pool":
             pl = empty_nhwc(B, co, s // 2, s // 2, bf, dev)
             t_f = run(lambda: K.conv3x3_relu_pool(x, wf, bias, y, pl))
+        elif kind == "bits":
+            gbo = K.gate_bits_alloc(y)
+            t_f = run(lambda: K.conv3x3_bits(x, wf, bias, y, 1, gate_bits_out=gbo))
         else:
             t_f = run(lambda: K.conv3x3(x, wf, bias, y, 1, 1))
-        t_d = run(lambda: K.conv3x3(gy, wd, None, dx, egate=x, egate_act=1))
+        if kind == "bits":
+            t_d = run(lambda: K.conv3x3(gy, wd, None, dx))
+        else:
+            gbi = torch.randint(-2**31, 2**31 - 1, (K.gate_bits_alloc(dx).numel(),), dtype=torch.int32, device=dev)
+            t_d = run(lambda: K.conv3x3_bits(gy, wd, None, dx, egate_bits=gbi))
         dw, db = torch.empty_like(w), torch.empty(co, device=dev)
         t_w = run(lambda: K.conv3x3_wgrad(x, gy, dw, db))
         tot["fwd"] += t_f; tot["dgrad"] += t_d; tot["wgrad"] += t_w
@@ -112,9 +124,9 @@ def main():
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     path = os.path.join(root, "gpurun_out", f"{tag}_layer_table.md")
     with open(path, "w") as fh:
-        fh.write(f"# {tag}: per-layer kernel table, cUNet {S}x{S} bf16 B={B}, every kernel stand-alone (median of 7 launches, hipEvents)\n\n")
+        fh.write(f"# {tag}: per-layer kernel table, cUNet {S}x{S} bf16 B={B}, every kernel stand-alone (median of 7 x (4 back-to-back launches / 4), hipEvents)\n\n")
         fh.write("MFMA convs (peak 2500 TFLOP/s dense bf16): forward = conv+bias+ReLU (+fused 2x2 max-pool on the encoder blocks' second conv); "
-                 "dgrad = data gradient with the ReLU gate of the upstream layer in the epilogue; wgrad = weight+bias gradient incl. its split-K reducer.\n\n")
+                 "dgrad = data gradient as the fused graph launches it (gate bits of the block's first-conv output in the epilogue for *.2, ungated for *.0); wgrad = weight+bias gradient incl. its split-K reducer.\n\n")
         fh.write("| layer | shape | GFLOP | fwd us | fwd TFLOP/s | dgrad us | dgrad TFLOP/s | wgrad us | wgrad TFLOP/s |\n|---|---|---|---|---|---|---|---|---|\n")
         for r in rows_conv:
             fh.write(f"| {r[0]} | {r[1]} | {r[2]:.1f} | {r[3]:.1f} | {r[4]:.0f} | {r[5]:.1f} | {r[6]:.0f} | {r[7]:.1f} | {r[8]:.0f} |\n")

@@ -420,8 +420,11 @@ class SpectralNormFn(Function):
         w_eff = torch.empty_like(w)
         _lib.call("wu_spectral_norm_fwd", w.data_ptr(), rows, cols, u.data_ptr(), v.data_ptr(), 1 if do_power_iteration else 0,
                   float(eps), sigma.data_ptr(), w_eff.data_ptr(), scratch.data_ptr(), stream_ptr())
-        # backward needs the u, v that defined sigma: clone (the buffers advance again on the next forward)
-        ctx.save_for_backward(w, u.clone(), v.clone(), sigma)
+        # backward needs the u, v that defined sigma: clone (the buffers advance again on the next forward) -- but only when there
+        # WILL be a backward: the generator update runs D with its parameters frozen (wu/train_step.py), evaluation() under no_grad;
+        # two tiny device copies per SN layer and forward were 146 hipMemcpyAsync per GAN iteration
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(w, u.clone(), v.clone(), sigma)
         return w_eff
 
     @staticmethod
