@@ -96,6 +96,13 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 __device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
+// 16 couts x 16 pixels x 32 channels (a whole K chunk of one tap): the shape of the one-wave-per-SIMD instances (round 3)
+__device__ __forceinline__ void mma16(f32x4_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+// accumulator storage of one (tile row, 32-pixel half... ) -- see M16 in the kernel
+template <bool M16_, int RPW_> struct AccT { using type = f32x16_t[RPW_][2]; };
+template <int RPW_> struct AccT<true, RPW_> { using type = f32x4_t[RPW_][2][4]; };
 
 // GATED: 0 = forward; 1 / 2 = the data-gradient form (a gate in the epilogue, no bias) with the gate as a tensor / as bits;
 // 3 = forward (ReLU) that also writes the gate bits of its output -- separate instances so that
@@ -103,6 +110,14 @@ __device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& 
 template <int NW, int GATED>
 __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a) {
     using Q = KW<NW>;
+    // M16 (the 4-wave, one-wave-per-SIMD instances): v_mfma_f32_16x16x32_bf16 instead of 32x32x16.  Same flops, same LDS fragment
+    // traffic (12 16-byte reads per tap and wave); measured on the identical data flow, the 16x16x32 stream runs the Cin >= 256
+    // layers 5.5-6.5 % faster (the chip holds a higher clock on it: MI355X_MICROARCH.md, DVFS item 7), while the two-waves-per-SIMD
+    // instances gain nothing.  A lane then holds 4 consecutive couts of ONE pixel per accumulator (not 32 channels of a pixel
+    // half-row), so the tile's results are brought into the 32x32 epilogue's register layout through the LDS buffer that has just
+    // been computed from (bias + activation + bf16 packing happen before that hop; gates, pool, gate bits and the deferred
+    // stores after it are shared with the 8-wave instances).
+    constexpr bool M16 = NW == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -148,7 +163,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         const int i = (NW * j + wave) * 64 + lane;
         const int p = i >> 2, sl = i & 3;
         const int hy = p / K::HALO_W, hx = p - hy * K::HALO_W;
-        hoff[j] = p < K::HALO_PIX ? (unsigned)(((hy * a.W + hx) * a.ldx + (sl ^ ((hx >> 2) & 3)) * 8) * 2) : kWuOOB;
+        // bank swizzle of the 16-byte channel slot, matched to the fragment reads: 32x32x16 reads 32 pixels x 2 slots per
+        // instruction, 16x16x32 reads 16 pixels x 4 slots (conflict-free iff {s(x), s(x+4)^1, s(x+8)^1, s(x+12)} are distinct)
+        const int swz = M16 ? 2 * ((hx >> 2) & 1) : ((hx >> 2) & 3);
+        hoff[j] = p < K::HALO_PIX ? (unsigned)(((hy * a.W + hx) * a.ldx + (sl ^ swz) * 8) * 2) : kWuOOB;
     }
     // weights: row = i >> 2 = tap*64 + co, slot sl holds channel slot sl ^ swz(co): byte offset relative to the cout tile
     unsigned woff[Q::NWT];
@@ -157,7 +175,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         const int i = (NW * j + wave) * 64 + lane;
         const int row = i >> 2, sl = i & 3;
         const int tap = row >> 6, co = row & 63;
-        woff[j] = NW * j + wave < K::W_REAL ? (unsigned)(((tap * a.Cout + co) * a.Cin + (sl ^ ((co >> 2) & 3)) * 8) * 2) : kWuOOB;
+        const int swz = M16 ? 2 * ((co >> 2) & 1) : ((co >> 2) & 3);
+        woff[j] = NW * j + wave < K::W_REAL ? (unsigned)(((tap * a.Cout + co) * a.Cin + (sl ^ swz) * 8) * 2) : kWuOOB;
     }
 
     // descriptors of the tile whose chunks are currently being FETCHED (one tile ahead at tile boundaries): scalar state
@@ -210,6 +229,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) b_lane[ks] = K::H_BYTES + l31 * 64 + (((2 * ks + lh) ^ ((l31 >> 2) & 3)) << 4);
 
+    // M16 fragments: lane (l15 = lane & 15, q = lane >> 4) reads pixel x0 + l15 (or cout 16 cb + l15), 16-byte K slot q
+    const int l15 = lane & 15, q16 = lane >> 4;
+    int a16_lane[3], b16_lane = 0;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+        a16_lane[kw] = ((Q::RPW * wave) * K::HALO_W + l15 + kw) * 64 + ((q16 ^ (2 * (((l15 + kw) >> 2) & 1))) << 4);
+    b16_lane = K::H_BYTES + l15 * 64 + ((q16 ^ (2 * ((l15 >> 2) & 1))) << 4);
+
     unsigned long long t_wait = 0, t_comp = 0, t_comp_rest = 0, t_epi_b1 = 0, t_epi_b2 = 0, t_epi_s = 0, t_mark = 0;
 #define WU_STAMP(acc_var) do { if (a.dbg) { const unsigned long long t_ = __builtin_readcyclecounter(); acc_var += t_ - t_mark; t_mark = t_; } } while (0)
     unsigned long long t_k0 = 0, t_r0 = 0;
@@ -250,16 +277,23 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
     for (int tile = t_begin; tile < t_end; tile += t_step) {
         // accumulators are kept TRANSPOSED (rows = cout, cols = pixels: the weight fragment is the MFMA A operand):
         // a lane then owns 4 consecutive channels of one pixel per register quad -> 8-byte epilogue writes
-        f32x16_t acc[Q::RPW][2];
+        typename AccT<M16, Q::RPW>::type acc;            // 32x32: [row][cout half] x 16; M16: [row][pixel half][cout quarter] x 4
 #pragma unroll
         for (int mi = 0; mi < Q::RPW; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < 2; ++ni) {
+                if constexpr (M16) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+                    for (int cb = 0; cb < 4; ++cb) acc[mi][ni][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+                }
+            }
 
         // bias of this tile's 64 channels, in the transposed-accumulator layout (4 consecutive channels per register quad)
         float4 bvq[2][4];
+        float4 b16[4];                // M16: bias of couts 16 cb + 4 q .. + 3
         uint4 egv[Q::RPW][2][2];      // gate values (dgrad): prefetched in the last chunk
         unsigned egb[Q::RPW];         // gate bits (dgrad): one dword per row
         // One K chunk.  Chunk 0 is a separate instance of this code (FIRST): only it issues the previous tile's deferred stores, and
@@ -270,8 +304,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         // to the DMA), and they execute BEHIND the first fragment reads of the next chunk -- the pipeline no longer drains at the
         // end of every chunk and refills (one LDS round trip with the matrix pipe idle, for both waves of a SIMD at once) behind
         // every barrier.  Same MFMA order per accumulator: results are bit-identical.  Only a tile's last chunk runs all 18 steps.
-        constexpr int RING = NW == 8 ? 3 : 2, CARRY = NW == 8 ? 2 : 1;     // steps carried: 16, 17 / 17
-        uint4 raf[RING][Q::RPW], rbf[RING][2];
+        constexpr int RING = 3, CARRY = NW == 8 ? 2 : 1;     // carried: (tap, k-step) steps 16, 17 at 8 waves; tap 8 at 4 waves (M16)
+        uint4 raf[RING][Q::RPW], rbf[RING][2];               // 32x32x16 fragments (8 waves)
+        uint4 xr[RING][Q::RPW][2], wr[RING][4];              // 16x16x32 fragments (M16): [row][pixel half], [cout quarter]
         auto do_chunk = [&](const int c, auto first_tag, auto last_tag) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
             constexpr bool LAST = decltype(last_tag)::value;      // the tile's last chunk: nothing is carried out of it
@@ -295,11 +330,17 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
             WU_STAMP(t_epi_b2);  // (diagnostic) chunk-top barrier time is folded into the 'barrier2' slot
             if (last && (GATED == 0 || GATED == 3)) {      // requested in the LAST chunk: lands under its MFMAs, and its registers are free for `ov` before
                 const int ct_ = cur.ct;
+                if constexpr (M16) {
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                    for (int cb = 0; cb < 4; ++cb)
+                        b16[cb] = a.bias ? *(const float4*)(a.bias + ct_ * 64 + 16 * cb + 4 * q16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        bvq[ni][g] = a.bias ? *(const float4*)(a.bias + ct_ * 64 + 32 * ni + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            bvq[ni][g] = a.bias ? *(const float4*)(a.bias + ct_ * 64 + 32 * ni + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
             if (last && more) { fetch = advance(fetch); set_fetch_tile(fetch); }
             // the gate values of this tile's outputs are requested at the start of its LAST chunk: they land under the MFMAs
@@ -386,53 +427,64 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
-                auto (&af) = raf;
-                auto (&bf) = rbf;
-                // ONE wave per SIMD: nothing else fills the matrix pipe while this wave issues loads, so the stream is pinned
-                // instruction by instruction: after MFMA m of step s comes fragment read m of step s+1 (6 reads over the
-                // first 6 of 8 MFMAs), the DMA pieces ride behind the last MFMA; the whole chunk is one basic block.
-                constexpr int NF = Q::RPW + 2, NM = 2 * Q::RPW;
-                auto load_frag = [&](int step, int f, uint4 (&af_)[Q::RPW], uint4 (&bf_)[2]) __attribute__((always_inline)) {
-                    const int tap = step >> 1, ks = step & 1, kh = tap / 3, kw = tap % 3;
-                    // order B0, A0, B1, A1, A2, ...: the first MFMA of the next step needs (A0, B0)
-                    if (f == 0 || f == 2) bf_[f >> 1] = *(const uint4*)(lds + b_lane[ks] + (tap * 64 + 32 * (f >> 1)) * 64);
-                    else {
-                        const int mi = f == 1 ? 0 : f - 2;
-                        af_[mi] = *(const uint4*)(lds + a_lane[kw][ks] + ((mi + kh) * K::HALO_W + kw) * 64);
+                // ONE wave per SIMD, 16x16x32: a step is a whole TAP (all 32 channels of the chunk): 12 fragments (4 weight quarters,
+                // 4 rows x 2 pixel halves) feed 32 MFMAs.  Nothing else fills the matrix pipe while this wave issues loads, so the
+                // stream is pinned instruction by instruction: after MFMA m of tap t comes fragment read m of tap t+1 (12 reads over
+                // the first 12 of 32 MFMAs, in the order the next tap's MFMAs need them); DMA pieces and the previous tile's deferred
+                // stores ride behind MFMAs 15 and 31.  Ring of three fragment sets (slot = tap % 3: tap 8, carried over the barrier
+                // in slot 2, leaves slots 0 and 1 to the next chunk's first taps).
+                constexpr int NF = 12, NM = 32;
+                auto load_frag = [&](int tap, int f, uint4 (&xf)[Q::RPW][2], uint4 (&wf)[4]) __attribute__((always_inline)) {
+                    const int kh = tap / 3, kw = tap % 3;
+                    // arrival order = use order (MFMA m: cout quarter m >> 3, row (m & 7) >> 1, pixel half m & 1): W0, X00 .. X31, W1, W2, W3
+                    if (f == 0 || f >= 9) {
+                        const int cb = f == 0 ? 0 : f - 8;
+                        wf[cb] = *(const uint4*)(lds + b16_lane + (tap * 64 + 16 * cb) * 64);
+                    } else {
+                        const int mi = (f - 1) >> 1, ph = (f - 1) & 1;
+                        xf[mi][ph] = *(const uint4*)(lds + a16_lane[kw] + ((mi + kh) * K::HALO_W + 16 * ph) * 64);
                     }
+                };
+                auto mma_m = [&](int m, int slot) __attribute__((always_inline)) {
+                    const int cb = m >> 3, mi = (m & 7) >> 1, ph = m & 1;
+                    mma16(acc[mi][ph][cb], wr[slot][cb], xr[slot][mi][ph]);                 // D^T (couts x pixels) = W * X^T
                 };
                 const unsigned kill = more ? 0u : kWuOOB;
                 if constexpr (FIRST) {
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) load_frag(0, f, af[0], bf[0]);
+                    for (int f = 0; f < NF; ++f) load_frag(0, f, xr[0], wr[0]);
                 } else {
-                    // carried in: step 17 of the previous chunk (ring slot 1); its MFMAs cover the fragment reads of step 0
+                    // carried in: tap 8 of the previous chunk (ring slot 2); its MFMAs cover the fragment reads of tap 0
 #pragma unroll
                     for (int m = 0; m < NM; ++m) {
-                        mma(acc[m >> 1][m & 1], bf[1][m & 1], af[1][m >> 1]);
-                        if (m < NF) load_frag(0, m, af[0], bf[0]);
+                        mma_m(m, 2);
+                        if (m < NF) load_frag(0, m, xr[0], wr[0]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
 #pragma unroll
-                for (int step = 0; step < 18; ++step) {
-                    const int cur = step & 1;
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int cur = tap % 3, nx = (tap + 1) % 3;
 #pragma unroll
                     for (int m = 0; m < NM; ++m) {
-                        if (LAST || step < 18 - CARRY) mma(acc[m >> 1][m & 1], bf[cur][m & 1], af[cur][m >> 1]);   // step 17: carried
-                        if (step + 1 < 18 && m < NF) load_frag(step + 1, m, af[cur ^ 1], bf[cur ^ 1]);
-                        // 20 pieces, two behind the last MFMA of steps 0..9 (four per step over steps 0..4 measured slower)
-                        if (m == NM - 1 && 2 * step < Q::NP) {
-                            issue_piece(2 * step, c1, nxt, kill);
-                            if (2 * step + 1 < Q::NP) issue_piece(2 * step + 1, c1, nxt, kill);
+                        if (LAST || tap < 9 - CARRY) mma_m(m, cur);                             // tap 8: carried into the next chunk
+                        if (tap + 1 < 9 && m < NF) load_frag(tap + 1, m, xr[nx], wr[nx]);
+                        // 20 DMA pieces, two behind MFMAs 15 and 31 of taps 0..4
+                        if ((m == 15 || m == NM - 1) && 4 * tap < Q::NP) {
+                            const int j0 = 4 * tap + (m == 15 ? 0 : 2);
+                            if (j0 < Q::NP) issue_piece(j0, c1, nxt, kill);
+                            if (j0 + 1 < Q::NP) issue_piece(j0 + 1, c1, nxt, kill);
                         }
-                        // the previous tile's 16 outputs: two stores behind the last MFMA of steps 10 .. 17 (after the DMA pieces)
-                        static_assert(2 * 10 >= Q::NP || NW != 4, "deferred stores must follow the last DMA piece");
-                        if (FIRST && m == NM - 1 && ov_pending && step >= 10 && 2 * (step - 10) + 1 < Q::NST) {
-                            store_ov(2 * (step - 10));
-                            store_ov(2 * (step - 10) + 1);
+                        // the previous tile's 16 outputs: two stores behind MFMAs 15 and 31 of taps 5..8 (after the DMA pieces)
+                        static_assert(4 * 5 >= Q::NP || NW != 4, "deferred stores must follow the last DMA piece");
+                        if (FIRST && (m == 15 || m == NM - 1) && ov_pending && tap >= 5) {
+                            const int k0 = 4 * (tap - 5) + (m == 15 ? 0 : 2);
+                            if (k0 + 1 < Q::NST) { store_ov(k0); store_ov(k0 + 1); }
                         }
-                        if (GATED == 3 && FIRST && m == NM - 1 && ovb_pending && step >= 18 - Q::RPW) store_ovb(step - (18 - Q::RPW));
+                        if (GATED == 3 && FIRST && m == NM - 1 && ovb_pending && tap == 8) {
+#pragma unroll
+                            for (int mi = 0; mi < Q::RPW; ++mi) store_ovb(mi);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -444,6 +496,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         do_chunk(0, std::true_type{}, std::false_type{});
         for (int c = 1; c + 1 < nchunks; ++c) do_chunk(c, std::false_type{}, std::false_type{});
         do_chunk(nchunks - 1, std::false_type{}, std::true_type{});
+        // M16: every wave is done with the fragment reads of the tile's last chunk -- its LDS buffer becomes the transpose scratch
+        // of the epilogue (one extra workgroup barrier per tile; a tile of these instances is 8-24 chunks long)
+        if constexpr (M16) __syncthreads();
 
         // ---- epilogue of this tile (its last chunk sat in buffer buf^1, now free; buffer `buf` is receiving the next
         //      tile's chunk 0): bias + activation in fp32, packed to bf16 in registers (`ov`); the stores follow later ----
@@ -461,6 +516,33 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         auto epi_store = [&](auto act_tag, auto eg_tag, auto pool_tag) __attribute__((always_inline)) {
             constexpr int ACT = decltype(act_tag)::value, EG = decltype(eg_tag)::value;
             constexpr bool POOL = decltype(pool_tag)::value;       // only with ACT == RELU (non-negative outputs)
+            // M16: the 16x16 accumulators (4 couts of one pixel per lane) -> bias, activation, bf16 -> this wave's slice of the LDS
+            // buffer the tile's last chunk was computed from, [row][pixel] rows of 64 channels at a 144-byte pitch (conflict-free for
+            // the 8-byte writes and the 16-byte reads); read back below, 16 bytes per (pixel l31, half lh), exactly the register
+            // contents the 32x32 path gets from v_permlane32_swap.  A wave only reads what it wrote itself.
+            constexpr int SCR_PITCH = 144;
+            char* const scr = smem + (buf ^ 1) * K::BUF + wave * (Q::RPW * 32 * SCR_PITCH);
+            if constexpr (M16) {
+                static_assert(NW * Q::RPW * 32 * SCR_PITCH <= K::BUF, "transpose scratch must fit the free LDS buffer");
+#pragma unroll
+                for (int mi = 0; mi < Q::RPW; ++mi)
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb) {
+                            const float4 bv = (GATED == 1 || GATED == 2) ? make_float4(0.f, 0.f, 0.f, 0.f) : b16[cb];
+                            f32x2_t v0 = f32x2_t{acc[mi][ph][cb][0], acc[mi][ph][cb][1]} + f32x2_t{bv.x, bv.y};
+                            f32x2_t v1 = f32x2_t{acc[mi][ph][cb][2], acc[mi][ph][cb][3]} + f32x2_t{bv.z, bv.w};
+                            if (ACT == WU_ACT_LEAKY) {      // max(v, 0.2 v)
+                                const f32x2_t s0_ = v0 * 0.2f, s1_ = v1 * 0.2f;
+                                v0 = f32x2_t{fmaxf(v0.x, s0_.x), fmaxf(v0.y, s0_.y)};
+                                v1 = f32x2_t{fmaxf(v1.x, s1_.x), fmaxf(v1.y, s1_.y)};
+                            }
+                            uint2 o = make_uint2(pack_bf16x2(v0.x, v0.y), pack_bf16x2(v1.x, v1.y));
+                            if (ACT == WU_ACT_RELU) { o.x = relu_bf16x2(o.x); o.y = relu_bf16x2(o.y); }
+                            *(uint2*)(scr + (mi * 32 + 16 * ph + l15) * SCR_PITCH + (16 * cb + 4 * q16) * 2) = o;
+                        }
+            }
             unsigned gb[Q::RPW];
 #pragma unroll
             for (int i = 0; i < Q::RPW; ++i) gb[i] = 0u;
@@ -475,6 +557,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
 #pragma unroll
                         for (int r = 0; r < 2; ++r) {
                             const int mi = 2 * mp + r;
+                            uint4 v;
+                            if constexpr (M16) {
+                                v = *(const uint4*)(scr + (mi * 32 + l31) * SCR_PITCH + (32 * ni + 8 * g + 8 * lh) * 2);
+                            } else {
                             uint32_t o[2][2];
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
@@ -494,7 +580,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                             // vdst = group g, src = group g+1 (cdna guide T21)
                             const auto s0 = __builtin_amdgcn_permlane32_swap(o[0][0], o[1][0], false, false);
                             const auto s1 = __builtin_amdgcn_permlane32_swap(o[0][1], o[1][1], false, false);
-                            uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                            v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                            }
                             if (GATED == 2) {
                                 // byte k of the row's gate word: element e of this 16-byte group passes iff bit e is set
                                 const int by = (int)(egb[mi] >> (8 * (2 * ni + (g >> 1))));
