@@ -278,8 +278,14 @@ def main():
                                        "frac": round(iso[dom]["flops"] / (iso[dom]["ms"] * 1e-3) / 1e12 / peak, 4),
                                        "avg_launch_ms": round(iso[dom]["ms"] / iso[dom]["launches"], 4),
                                        "note": "same kernels with the weight-gradient side stream off (3 extra steps after the timed region)"}),
-                    "other_kernels": {_lib.FAMILY_KERNEL[f]: {"ms_per_step": round(stats[f]["ms"] / a.steps, 3),
-                                                             "TFLOP/s": round(stats[f]["flops"] / max(stats[f]["ms"], 1e-9) / 1e9, 1)}
+                    # the estimator's pointwise GEMMs are HBM-bound (K = 64 ... 2048 at 2-16 k rows: 30-110 flop per algorithmic
+                    # byte): their roofline is bandwidth, so they are reported in GB/s of algorithmic bytes as well
+                    "other_kernels": {_lib.FAMILY_KERNEL[f]: dict({"ms_per_step": round(stats[f]["ms"] / a.steps, 3),
+                                                                   "TFLOP/s": round(stats[f]["flops"] / max(stats[f]["ms"], 1e-9) / 1e9, 1)},
+                                                                  **({"launches_per_step": round(stats[f]["launches"] / a.steps, 1),
+                                                                      "GB/s": round(stats[f]["bytes"] / max(stats[f]["ms"], 1e-9) / 1e6, 1),
+                                                                      "frac_of_8TBps": round(stats[f]["bytes"] / max(stats[f]["ms"], 1e-9) / 1e6 / 8000.0, 4)}
+                                                                     if f == _lib.FAM_CONV1X1 else {}))
                                       for f in families}}
 
     if rank == 0:

@@ -61,7 +61,7 @@ CONV_SHAPES = [
 def test_conv3x3_forward(p, shape, act):
     from wu import functional as WF
     n, cin, cout, h, w, stride = shape
-    if act == 2 and stride == 1 and cin != 64:
+    if act == 2 and stride == 1 and cin not in (64, 256):      # 64: the 8-wave LDS-DMA instance, 256: the 4-wave 16x16x32 one
         pytest.skip("leaky covered on a subset")
     x = _round(_rand((n, cin, h, w), 1), p)
     wt = _round(_rand((cout, cin, 3, 3), 2, -0.1, 0.1), p)

@@ -283,6 +283,112 @@ __global__ __launch_bounds__(256) void stem7x7_fwd_kernel(const float* __restric
     }
 }
 
+// bf16 stem on the matrix cores (round 3).  The VALU kernel above reads 147 x 16 float4 weight rows from LDS per output pixel and
+// is LDS-bound (510 us for B = 64 at 256x256, 185 MB: 0.36 TB/s); as an implicit GEMM the stem is ~20 GFLOP and HBM-bound.
+//   rows (MFMA B operand, transposed scheme of conv3x3_mfma_v2): 32 output pixels of one output row; couts: 2 x 32 (A operand);
+//   K ordered (kh, c, kw padded 7 -> 8): 21 groups of 8 + one zero group = 11 k-steps of 16.  A lane's 8 k-values of a group are
+//   8 CONSECUTIVE image columns of one channel row -- the bf16 patch row is read with four 4-byte LDS reads (the window of output
+//   column ox starts at patch column 2 ox: even, so 4-byte aligned; consecutive lanes read consecutive dwords: conflict-free).
+//   The weight fragments (11 k-steps x 2 cout halves) are built once per workgroup from the OIHW fp32 tensor and live in registers;
+//   workgroups are persistent over (image, 8 x 32-pixel tile) items.
+constexpr int kSP16 = 72;       // bf16 patch pitch: 69 real columns + column 69 (kw = 7, zero weight: must only be finite) + pad
+
+__global__ __launch_bounds__(256, 2) void stem7x7_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                  bf16_t* __restrict__ y, int ldy, int N, int H, int W, int Ho, int Wo, int act, int ntiles) {
+    __shared__ __attribute__((aligned(16))) bf16_t patch[3][kSPH][kSP16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int tiles_x = cdiv_dev(Wo, kSTW), tiles_y = cdiv_dev(Ho, kSTH);
+
+    // ---- weight fragments: k-step s, lane half lh -> group g = 2 s + lh = (kh, c); element j = kw (kw = 7 and g = 21: zero) ----
+    uint4 wa[11][2];
+#pragma unroll
+    for (int s_ = 0; s_ < 11; ++s_)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int g = 2 * s_ + lh, kh = g / 3, c = g - 3 * kh, co = 32 * h + l31;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (g < 21 && j < 7) ? w[(co * 3 + c) * 49 + kh * 7 + j] : 0.f;
+            wa[s_][h] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        }
+    // bias in the transposed-accumulator layout: register quad q of half h holds couts 32 h + 8 q + 4 lh .. + 3
+    float4 bq[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[h][q] = bias ? *(const float4*)(bias + 32 * h + 8 * q + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // per-lane patch byte offset of (group row of k-step s, this lane's window start): row = c * 21 + kh (+ 2 * local output row)
+    int xoff[11];
+#pragma unroll
+    for (int s_ = 0; s_ < 11; ++s_) {
+        const int g = min(2 * s_ + lh, 20), kh = g / 3, c = g - 3 * kh;      // g = 21 (zero weights) re-reads group 20
+        xoff[s_] = ((c * kSPH + kh) * kSP16 + 2 * l31) * 2;
+    }
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int n = t / tiles_y;
+        const int oh0 = ty * kSTH, ow0 = tx * kSTW;
+        const int ih0 = 2 * oh0 - 3, iw0 = 2 * ow0 - 3;
+        __syncthreads();                                  // the previous tile's fragment reads are done
+        for (int i = tid; i < 3 * kSPH * kSP16; i += 256) {
+            const int px = i % kSP16, r = i / kSP16;
+            const int py = r % kSPH, c = r / kSPH;
+            const int ih = ih0 + py, iw = iw0 + px;
+            const bool ok = px < kSPW && ih >= 0 && ih < H && iw >= 0 && iw < W;
+            const float v = x[((size_t)(n * 3 + c) * H + min(max(ih, 0), H - 1)) * W + min(max(iw, 0), W - 1)];
+            patch[c][py][px] = f32_to_bf16(ok ? v : 0.f);
+        }
+        __syncthreads();
+        f32x16_t acc[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[r][h][i] = 0.f;
+        const char* pb = (const char*)&patch[0][0][0];
+#pragma unroll
+        for (int s_ = 0; s_ < 11; ++s_) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const char* p = pb + xoff[s_] + (2 * (2 * wave + r)) * kSP16 * 2;       // output row 2 wave + r -> patch rows 2 (2 wave + r) + kh
+                const uint4 xb = make_uint4(*(const uint32_t*)p, *(const uint32_t*)(p + 4), *(const uint32_t*)(p + 8), *(const uint32_t*)(p + 12));
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    acc[r][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wa[s_][h]), __builtin_bit_cast(bf16x8_t, xb), acc[r][h], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: bias + activation, bf16, v_permlane32_swap pairs the half-waves' 4-channel groups into 16-byte stores ----
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int oh = oh0 + 2 * wave + r, ow = ow0 + l31;
+            const bool ok = oh < Ho && ow < Wo;
+            bf16_t* yp = y + ((size_t)(n * Ho + min(oh, Ho - 1)) * Wo + min(ow, Wo - 1)) * ldy;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    uint32_t o[2][2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float4 bv = bq[h][q + e];
+                        const int r0 = 4 * (q + e);
+                        o[e][0] = pack_bf16x2(act_apply(acc[r][h][r0 + 0] + bv.x, act), act_apply(acc[r][h][r0 + 1] + bv.y, act));
+                        o[e][1] = pack_bf16x2(act_apply(acc[r][h][r0 + 2] + bv.z, act), act_apply(acc[r][h][r0 + 3] + bv.w, act));
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(o[0][0], o[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(o[0][1], o[1][1], false, false);
+                    // lanes 0-31: channels 32 h + 8 q .. + 7 of their pixel, lanes 32-63: + 8 .. + 15
+                    if (ok) *(uint4*)(yp + 32 * h + 8 * q + 8 * lh) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+        }
+    }
+}
+
 // data gradient of the stem wrt the NCHW fp32 image: dx[n][c][ih][iw] = sum_{co, kh, kw : (ih+3-kh, iw+3-kw) even} dy[n][oh][ow][co] w[co][c][kh][kw]
 // 8 lanes per input pixel (each 8 of the 64 channels), the partial sums of the 3 image channels folded with xor shuffles.
 template <typename T>
@@ -486,6 +592,14 @@ extern "C" int wu_stem7x7_fwd(const float* x_nchw, const float* w_oihw, const fl
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;                     // (H + 6 - 7) / 2 + 1
     const long long grid = (long long)N * cdiv(Ho, kSTH) * cdiv(Wo, kSTW);
     WU_REQUIRE(grid < (1ll << 31), "stem7x7_fwd: grid too large");
+    if (dtype == WU_BF16 && (!bias || al16(bias))) {
+        // persistent: two workgroups per CU (registers), each builds its weight fragments once
+        const long long g2 = 2ll * wu_num_cus();
+        hipLaunchKernelGGL(stem7x7_fwd_mfma_kernel, dim3((unsigned)(grid < g2 ? grid : g2)), dim3(256), 0, (hipStream_t)stream,
+                           x_nchw, w_oihw, bias, (bf16_t*)y, ldy, N, H, W, Ho, Wo, act, (int)grid);
+        WU_LAUNCH_CHECK("stem7x7_fwd (mfma)");
+        return 0;
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(stem7x7_fwd_kernel<T>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
                                          x_nchw, w_oihw, bias, (T*)y, ldy, N, H, W, Ho, Wo, act));
     WU_LAUNCH_CHECK("stem7x7_fwd");
