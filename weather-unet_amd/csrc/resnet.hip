@@ -162,6 +162,74 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
 
     // ---- direct register epilogue: bias + residual in fp32, activation, gate, 8-byte (bf16) / 16-byte (fp32) stores ----
     const int os = a.out_stride;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        // Fast path (round 3), bf16 and unit output stride -- every pointwise conv of the forward pass: the fp32 sums of two
+        // adjacent 4-channel groups are paired across the half-waves with v_permlane32_swap BEFORE residual / activation / gate, so a
+        // lane owns 8 consecutive channels of its pixel: residual and gate arrive as ONE 16-byte load each (requested up front,
+        // one exposed round trip per tile), the result leaves as one 16-byte store -- half the memory instructions of the general
+        // path below, same arithmetic in the same order (bias, + residual, activation, gate; one rounding at the end).
+        if (os == 1) {
+            uint4 rq[2][2][2], eq[2][2][2];
+            bool okm[2];
+            const T* rp[2]; const T* ep[2]; T* yp[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const long long m = m0 + 64 * wave + 32 * mi + l31;
+                okm[mi] = m < a.M;
+                const long long p = okm[mi] ? m : 0;
+                rp[mi] = a.res ? (const T*)a.res + p * a.ldres + co0 + 8 * lh : nullptr;
+                ep[mi] = a.egate ? (const T*)a.egate + p * a.ldegate + co0 + 8 * lh : nullptr;
+                yp[mi] = (T*)a.y + p * a.ldy + co0 + 8 * lh;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        if (a.res) rq[mi][ni][gp] = *(const uint4*)(rp[mi] + 32 * ni + 16 * gp);
+                        if (a.egate) eq[mi][ni][gp] = *(const uint4*)(ep[mi] + 32 * ni + 16 * gp);
+                    }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        float lo[4], hi[4];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int g = 2 * gp + e;
+                            const float4 bv = a.bias ? *(const float4*)(a.bias + co0 + 32 * ni + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            float* d = e ? hi : lo;
+                            d[0] = acc[mi][ni][4 * g + 0] + bv.x; d[1] = acc[mi][ni][4 * g + 1] + bv.y;
+                            d[2] = acc[mi][ni][4 * g + 2] + bv.z; d[3] = acc[mi][ni][4 * g + 3] + bv.w;
+                        }
+                        float o[8];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            // lanes 0-31 keep group 2 gp and receive its upper four channels from lanes 32-63; lanes 32-63 the mirror
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo[i]), __float_as_uint(hi[i]), false, false);
+                            o[i] = __uint_as_float(sw[0]);
+                            o[4 + i] = __uint_as_float(sw[1]);
+                        }
+                        if (a.res) {
+                            float rv[8];
+                            unpack16<T>(rq[mi][ni][gp], rv);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] += rv[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = act_apply(o[e], a.act);
+                        if (a.egate) {
+                            float ev[8];
+                            unpack16<T>(eq[mi][ni][gp], ev);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = act_gate(o[e], ev[e], a.egate_act);
+                        }
+                        if (okm[mi]) *(uint4*)(yp[mi] + 32 * ni + 16 * gp) = pack16<T>(o);
+                    }
+            return;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const long long m = m0 + 64 * wave + 32 * mi + l31;
