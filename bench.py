@@ -210,8 +210,21 @@ def main():
     if gan is not None:       # discriminator stride-2 convs and the estimator's pointwise convs
         families += [_lib.FAM_CONV_S2, _lib.FAM_WGRAD_S2, _lib.FAM_CONV1X1]
     do_roof = (not a.no_roofline) and rank == 0
+    pre_stats = None
+    if do_roof and gan is not None:
+        # GAN workloads launch ~550 instrumented kernels per iteration and the hipEvent pair around each costs ~6 us of stream time
+        # (3.5 ms of a 31 ms iteration).  One extra, untimed, fully instrumented iteration finds the dominant family and gives the
+        # other families' figures; the timed region then brackets the dominant family only.
+        _lib.prof_begin(families, 1024 + 64)
+        step()
+        torch.cuda.synchronize()
+        pre_stats = {f: _lib.prof_query(f) for f in families}
+        _lib.prof_end()
+        families_timed = [max(pre_stats, key=lambda f: pre_stats[f]["ms"])]
+    else:
+        families_timed = families
     if do_roof:
-        _lib.prof_begin(families, (64 if gan is None else 1024) * a.steps + 64)
+        _lib.prof_begin(families_timed, (64 if gan is None else 1024) * a.steps + 64)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -226,7 +239,11 @@ def main():
     roof = None
     measured_flops = None
     if do_roof:
-        stats = {f: _lib.prof_query(f) for f in families}
+        stats = {f: _lib.prof_query(f) for f in families_timed}
+        if pre_stats is not None:           # the families not bracketed in the timed region: one untimed iteration, scaled to the run
+            for f in families:
+                if f not in stats:
+                    stats[f] = {k: v * a.steps for k, v in pre_stats[f].items()}
         measured_flops = sum(st["flops"] for st in stats.values())     # algorithmic conv FLOPs of the launches in the timed region
         _lib.prof_end()
         # In the training step the weight-gradient kernels run on a second HIP stream beside the data-gradient chain (faster
@@ -273,6 +290,8 @@ def main():
                     "avg_launch_ms": round(s["ms"] / s["launches"], 4),
                     "algorithmic_gflop_per_launch": round(s["flops"] / s["launches"] / 1e9, 3),
                     "share_of_step": round(s["ms"] / (dt * 1e3), 3),
+                    "instrumented": ("dominant family bracketed in the timed region; other_kernels from one untimed fully instrumented iteration"
+                                     if pre_stats is not None else "every launch of the listed families bracketed in the timed region"),
                     "single_stream": (None if iso is None or not iso[dom]["launches"] else
                                       {"achieved": round(iso[dom]["flops"] / (iso[dom]["ms"] * 1e-3) / 1e12, 2),
                                        "frac": round(iso[dom]["flops"] / (iso[dom]["ms"] * 1e-3) / 1e12 / peak, 4),
