@@ -11,6 +11,8 @@ are called on their own): inside the network every producer / consumer pair is o
     the max-pool backward kernel instead of a separate elementwise add;
   * reuse the zero-copy concat buffers and never touch autograd's per-op bookkeeping (45 ops -> 1 node).
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -23,6 +25,11 @@ RELU = K.ACT_RELU
 SIDE_STREAM_WGRAD = True
 # ReLU gates between a block's two convs travel as bits (1/16 of the tensor) where the LDS-DMA conv runs (A/B switch)
 GATE_BITS = True
+# where the FIRST conv's weight gradient (the last kernel of the backward chain) is launched: True = side stream (round 2), False =
+# main stream.  Round 3 trace: the side stream has no slack at the end of backward any more -- the last persistent weight gradient
+# (down1.2), its reducer and this kernel ran one after the other for 230 us after the main stream's last data gradient had finished;
+# on the main stream it runs beside that tail instead of behind it.
+C3_WGRAD_ON_SIDE = os.environ.get("WU_C3_WGRAD_SIDE", "0") == "1"
 _SIDE = {}
 SIDE_STREAM_LOG = []     # one entry per probe: which candidate won and the median timings (diagnostic)
 
@@ -269,12 +276,15 @@ class UNetFn(Function):
             else:
                 K.conv3x3(g_out_gated, wd[name + ".2"], None, g_mid, egate=mid, egate_act=RELU)
             if name == "dconv_down1":
-                # the first conv's weight gradient is the LAST kernel of the backward chain and nothing consumes it: it joins the
-                # other weight gradients on the side stream (which has slack) instead of extending the main stream's tail
+                # the first conv's weight gradient is the LAST kernel of the backward chain and nothing consumes it (see C3_WGRAD_ON_SIDE)
                 dw, db, acc = grad_bufs(0)
-                router.on_side(lambda: (K.conv3x3_c3_wgrad(xin, g_mid, dw, db, 1, code, accumulate=acc), done((name, 0), 0, dw, db)))
-                if side is not None:
-                    keep.append((xin, g_mid, dw, db))
+                if C3_WGRAD_ON_SIDE:
+                    router.on_side(lambda: (K.conv3x3_c3_wgrad(xin, g_mid, dw, db, 1, code, accumulate=acc), done((name, 0), 0, dw, db)))
+                    if side is not None:
+                        keep.append((xin, g_mid, dw, db))
+                else:
+                    K.conv3x3_c3_wgrad(xin, g_mid, dw, db, 1, code, accumulate=acc)
+                    done((name, 0), 0, dw, db)
                 return g_mid
             wgrad(name, 0, xin, g_mid)
             if not need_dx:
