@@ -50,7 +50,8 @@ int wu_cu_count(void);
  *   1: persistent tile loop on/off      2: LDS-DMA wgrad (0 off, 1 = 8 waves (default), 2 = 4 waves)      3: unused
  *   4: wgrad DMA issue spread over K-steps (default 1)   5: first conv (0 matrix cores in bf16 (default), 1 rows kernel, 2 VALU kernel)
  *   6: static priority for the younger wave half (default 1)   7: grid-strided tile assignment (default 1)
- *   8 / 9: marching AdaIN-upsample backward / forward (default 1)
+ *   8: AdaIN-upsample backward (0 = 16-tap gather, 1 = marching, columns per thread by size (default), 2 / 3 = one / two columns)
+ *   9: marching AdaIN-upsample forward (default 1)
  *   10: persistent-grid size override in compute units (0 = the device's count; experiments on CU-masked streams)
  *   11: Cin = 64 / one-cout-tile convs keep both weight chunks resident in LDS across a workgroup's tiles (default 1) */
 int wu_set_option(int key, int value);

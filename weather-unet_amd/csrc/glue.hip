@@ -584,13 +584,17 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_gather_kernel(
 // weights, and adds the result into the (at most two) low-res rows that row interpolates from -- the bilinear x2 operator is
 // separable, so its transpose is too.  Same sums, same parked g', same per-(n,c) statistics; the partial-sum slot of a workgroup is
 // its (column tile, row strip) index.
-template <typename T>
+// NCOL = low-resolution columns per thread.  2 (round 2): 6 loads per high-res row serve two columns (3 per column), but the kernel
+// needs 208 registers -> two waves per SIMD, and it is latency-bound (3 TB/s).  1 (round 3): 4 loads per row and column, half the
+// accumulators and row buffers -> twice the waves, each with its own row in flight.  Same sums in the same order per column.
+template <typename T, int NCOL>
 __global__ __launch_bounds__(256) void adain_upcat_bwd_march_kernel(
     const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx, const float* __restrict__ stats,
     T* __restrict__ gtmp, float* __restrict__ sums, int H, int W, int C, int rows_per_strip, int col_tiles,
     float sy, float sx, uint32_t thr, float keep_scale, uint64_t seed, const uint8_t* __restrict__ mbits) {
     constexpr int E = ElemTraits<T>::kPer16B;
-    constexpr int LP = 64 / E, PP = 256 / LP;          // lanes per pixel (64 channels), column pairs per workgroup
+    constexpr int LP = 64 / E, PP = 256 / LP;          // lanes per pixel (64 channels), column groups per workgroup
+    constexpr int NK = 2 * NCOL + 2;                   // high-res columns that touch a thread's NCOL low-res columns
     __shared__ float red[PP][64][2];
     __shared__ uint4 lut[E == 8 ? 256 : 1];
     const int tid = threadIdx.x;
@@ -607,46 +611,51 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_march_kernel(
     const int c0 = cg * 64 + cl * E;
     const int cpp = C / E, chunk = c0 / E;
     const int H2 = 2 * H, W2 = 2 * W, HW = H * W;
-    const int xa = 2 * (ctile * PP + pl), xb = xa + 1;               // this thread's two low-res columns
-    const bool va = xa < W, vb = xb < W;
+    const int x0 = NCOL * (ctile * PP + pl);                           // this thread's first low-res column
     const int y0 = strip * rows_per_strip, y1 = min(H, y0 + rows_per_strip);
-    float s1[E], s2[E], st[2 * E];
-    ldf<2 * E>(stats + 2 * (n * C + c0), st);
+    float s1[E], s2[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) s1[e] = s2[e] = 0.f;
-    // the 6 high-res columns 2*xa - 1 .. 2*xa + 4 and their weights towards xa (first four) and xb (last four)
-    int jx[6];
-    float wa[6], wb[6];
+    // the NK high-res columns 2*x0 - 1 .. 2*x0 + 2*NCOL and their weights towards column x0 + c (columns k = 2c .. 2c + 3)
+    int jx[NK];
+    float wgt[NCOL][4];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int j = 2 * xa - 1 + k;
+    for (int k = 0; k < NK; ++k) {
+        const int j = 2 * x0 - 1 + k;
         const int jc = min(max(j, 0), W2 - 1);
         const Lerp lx = src_index(jc, sx, W);
         const bool in = j == jc;
-        wa[k] = (in && k < 4) ? ((lx.i0 == xa ? lx.l0 : 0.f) + (lx.i1 == xa ? lx.l1 : 0.f)) : 0.f;
-        wb[k] = (in && k >= 2) ? ((lx.i0 == xb ? lx.l0 : 0.f) + (lx.i1 == xb ? lx.l1 : 0.f)) : 0.f;
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c)
+            if (k >= 2 * c && k < 2 * c + 4) {
+                const int xc = x0 + c;
+                wgt[c][k - 2 * c] = in ? ((lx.i0 == xc ? lx.l0 : 0.f) + (lx.i1 == xc ? lx.l1 : 0.f)) : 0.f;
+            }
         jx[k] = jc;
     }
-    // two pending low-res rows per column: acc?0 = row `cur`, acc?1 = row `cur + 1`
-    float a0[E], a1[E], b0[E], b1[E];
+    // two pending low-res rows per column: acc0 = row `cur`, acc1 = row `cur + 1`
+    float acc0[NCOL][E], acc1[NCOL][E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) a0[e] = a1[e] = b0[e] = b1[e] = 0.f;
+    for (int c = 0; c < NCOL; ++c)
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc0[c][e] = acc1[c][e] = 0.f;
     const int r_begin = max(0, 2 * y0 - 1), r_end = min(H2 - 1, 2 * y1);           // rows that can touch [y0, y1)
     int cur = src_index(r_begin, sy, H).i0;
 
-    auto emit = [&](int yy, const float* ga, const float* gb) __attribute__((always_inline)) {
+    auto emit = [&](int yy, const float (&ga)[NCOL][E]) __attribute__((always_inline)) {
         if (yy < y0 || yy >= y1) return;
         const size_t p = (size_t)n * HW + (size_t)yy * W;
+        float st[2 * E];
+        ldf<2 * E>(stats + 2 * (n * C + c0), st);
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const int xx = side ? xb : xa;
-            if (!(side ? vb : va)) continue;
-            const float* g = side ? gb : ga;
+        for (int c = 0; c < NCOL; ++c) {
+            const int xx = x0 + c;
+            if (xx >= W) continue;
             float gs[E], xv[E];
             unpack16<T>(*(const uint4*)(x + (p + xx) * ldx + c0), xv);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                gs[e] = thr < 0x10000u ? g[e] * keep_scale : g[e];
+                gs[e] = thr < 0x10000u ? ga[c][e] * keep_scale : ga[c][e];
                 s1[e] += gs[e];
                 s2[e] += gs[e] * ((xv[e] - st[2 * e]) * st[2 * e + 1]);
             }
@@ -654,14 +663,14 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_march_kernel(
         }
     };
 
-    if (va) {
-        // the loads of row r + 1 are issued before row r is reduced: one memory round trip per row pair is always in flight
-        uint4 dvn[6];
-        uint32_t bvn[6];
+    if (x0 < W) {
+        // the loads of row r + 1 are issued before row r is reduced: one memory round trip per row is always in flight
+        uint4 dvn[NK];
+        uint32_t bvn[NK];
         auto load_row = [&](int r) __attribute__((always_inline)) {
             const size_t rp = (size_t)(n * H2 + r) * W2;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
+            for (int k = 0; k < NK; ++k) {
                 dvn[k] = *(const uint4*)(dy + (rp + jx[k]) * lddy + c0);
                 bvn[k] = (thr < 0x10000u && mbits) ? mbits[(rp + jx[k]) * cpp + chunk] : 0u;
             }
@@ -669,24 +678,28 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_march_kernel(
         load_row(r_begin);
         for (int r = r_begin; r <= r_end; ++r) {
             const Lerp ly = src_index(r, sy, H);
-            uint4 dv[6];
-            uint32_t bv[6];
+            uint4 dv[NK];
+            uint32_t bv[NK];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) { dv[k] = dvn[k]; bv[k] = bvn[k]; }
+            for (int k = 0; k < NK; ++k) { dv[k] = dvn[k]; bv[k] = bvn[k]; }
             load_row(min(r + 1, r_end));
             // retire the rows no later high-res row can touch
             while (cur < ly.i0) {
-                emit(cur, a0, b0);
+                emit(cur, acc0);
 #pragma unroll
-                for (int e = 0; e < E; ++e) { a0[e] = a1[e]; b0[e] = b1[e]; a1[e] = 0.f; b1[e] = 0.f; }
+                for (int c = 0; c < NCOL; ++c)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) { acc0[c][e] = acc1[c][e]; acc1[c][e] = 0.f; }
                 ++cur;
             }
             const size_t rowpix = (size_t)(n * H2 + r) * W2;
-            float ta[E], tb[E];
+            float t[NCOL][E];
 #pragma unroll
-            for (int e = 0; e < E; ++e) ta[e] = tb[e] = 0.f;
+            for (int c = 0; c < NCOL; ++c)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
+                for (int e = 0; e < E; ++e) t[c][e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
                 float d[E];
                 if (thr < 0x10000u) {
                     if (mbits && E == 8) {
@@ -706,25 +719,25 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_march_kernel(
                 } else {
                     unpack16<T>(dv[k], d);
                 }
-                if (k < 4) {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) ta[e] = fmaf(wa[k], d[e], ta[e]);
-                }
-                if (k >= 2) {
+                for (int c = 0; c < NCOL; ++c)
+                    if (k >= 2 * c && k < 2 * c + 4) {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) tb[e] = fmaf(wb[k], d[e], tb[e]);
-                }
+                        for (int e = 0; e < E; ++e) t[c][e] = fmaf(wgt[c][k - 2 * c], d[e], t[c][e]);
+                    }
             }
             // vertical: this row interpolates from low-res rows i0 (weight l0) and i1 (weight l1; i1 == i0 on the last row)
             const float l1w = ly.i1 != ly.i0 ? ly.l1 : 0.f, l0w = ly.i1 != ly.i0 ? ly.l0 : ly.l0 + ly.l1;
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                a0[e] = fmaf(l0w, ta[e], a0[e]); b0[e] = fmaf(l0w, tb[e], b0[e]);
-                a1[e] = fmaf(l1w, ta[e], a1[e]); b1[e] = fmaf(l1w, tb[e], b1[e]);
-            }
+            for (int c = 0; c < NCOL; ++c)
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    acc0[c][e] = fmaf(l0w, t[c][e], acc0[c][e]);
+                    acc1[c][e] = fmaf(l1w, t[c][e], acc1[c][e]);
+                }
         }
-        emit(cur, a0, b0);
-        emit(cur + 1, a1, b1);
+        emit(cur, acc0);
+        emit(cur + 1, acc1);
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -1082,20 +1095,28 @@ extern "C" int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int l
     const int pp = 256 / (64 / (16 / esz));       // pixels (gather) / column pairs (march) per workgroup
     float* partials = sums + (size_t)N * C * 2;
     int splits;
-    // marching formulation: workgroup = (64 channels, 2*pp low-res columns, a strip of rows); its partial-sum slot = (column tile, strip)
-    const int col_tiles = cdiv(W, 2 * pp);
+    // marching formulation: workgroup = (64 channels, ncol*pp low-res columns, a strip of rows); its partial-sum slot = (column tile, strip)
+    // option 8: 0 = 16-tap gather, 1 = march with the column count chosen by size (default), 2 / 3 = always one / two columns per thread.
+    // One column per thread (3 waves per SIMD instead of 2) wins on the small levels, where a strip is short and the prologue and the
+    // row round trips dominate (64 -> 32: 108 -> 88 us, 128 -> 64: 160 -> 149 us); two columns (3 loads per column instead of 4) on 256 -> 128
+    // (292 vs 310 us)
+    const int opt8 = g_wu_opt[WU_OPT_ADAIN_BWD_MARCH];
+    const int ncol = (opt8 == 2 || (opt8 == 1 && W <= 64)) ? 1 : 2;
+    const int col_tiles = cdiv(W, ncol * pp);
     const bool march = g_wu_opt[WU_OPT_ADAIN_BWD_MARCH] && col_tiles <= kMaxSplits;
     if (march) {
         int strips = kMaxSplits / col_tiles;
-        const int want = cdiv(2048, N * (C / 64) * col_tiles);      // enough workgroups to fill the chip
+        const int want = cdiv(2048 * (3 - ncol), N * (C / 64) * col_tiles);      // enough workgroups to fill the chip
         if (strips > want) strips = want;
         if (strips > cdiv(H, 4)) strips = cdiv(H, 4);               // at least 4 low-res rows per strip (each strip re-reads a 1-row halo)
         if (strips < 1) strips = 1;
         const int rows_per_strip = cdiv(H, strips);
         strips = cdiv(H, rows_per_strip);
         splits = col_tiles * strips;
-        DISPATCH_T(dtype, hipLaunchKernelGGL(adain_upcat_bwd_march_kernel<T>, dim3(C / 64, splits, N), dim3(256), 0, s, (const T*)dy, lddy, (const T*)x, ldx,
-                                             stats, (T*)gtmp, partials, H, W, C, rows_per_strip, col_tiles, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), seed, mask_bits));
+#define WU_MARCH(NC) DISPATCH_T(dtype, hipLaunchKernelGGL((adain_upcat_bwd_march_kernel<T, NC>), dim3(C / 64, splits, N), dim3(256), 0, s, (const T*)dy, lddy, (const T*)x, ldx, \
+                                             stats, (T*)gtmp, partials, H, W, C, rows_per_strip, col_tiles, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), seed, mask_bits))
+        if (ncol == 1) WU_MARCH(1); else WU_MARCH(2);
+#undef WU_MARCH
     } else {
         splits = cdiv(2048, N * (C / 64));
         if (splits > cdiv(HW, pp)) splits = cdiv(HW, pp);
