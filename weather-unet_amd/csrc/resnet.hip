@@ -21,7 +21,6 @@ __host__ __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b -
 // =================================================================================================
 // 1x1 conv = GEMM   y[m][co] = act(sum_ci x[row(m)][ci] * w[co][ci] + bias[co] + residual[m][co]) [* act'(egate[m][co])]
 // =================================================================================================
-constexpr int kTM = 256;        // pixels per workgroup
 constexpr int kTN = 64;         // output channels per workgroup
 constexpr int kKB = 128;        // bytes of K staged per step and row (64 bf16 / 32 fp32 channels)
 
@@ -60,23 +59,30 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
     o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
 }
 
-// LDS image: 128-byte rows, the eight 16-byte slots of a row XOR-swizzled with (row & 7): a ds_read_b128 of 8 consecutive rows at
-// one logical slot touches all 32 banks once
-__device__ __forceinline__ int pw_off(int row, int slot) { return row * kKB + ((slot ^ (row & 7)) << 4); }
+// LDS image: 128-byte rows, the eight 16-byte slots of a row XOR-swizzled with ((row >> 1) & 7).  A ds_read_b128 is served in four
+// groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32) over 64 banks, i.e. 16 sixteen-byte columns of which
+// a 128-byte row covers 8 (even rows the lower, odd rows the upper half): the 8 even and the 8 odd rows of a group must land in 8
+// different slots.  (row & 7), the round-2 swizzle, puts rows 12 and 20, 13 and 21 ... of a group in the same slot: 2-way conflicts on
+// half the fragment reads (SQ_LDS_BANK_CONFLICT = 31 % of SQ_LDS_IDX_ACTIVE on every shape, scratch/pmc_pw.sh); (row >> 1) & 7 is
+// distinct over each group's rows of one parity.
+__device__ __forceinline__ int pw_off(int row, int slot) { return row * kKB + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
+// TM = pixels per workgroup: 256 (two 40-KiB stages, 2 workgroups per CU) or 128 (two 24-KiB stages, 3 per CU: shorter chains of exposed
+// round trips per workgroup and more of them in flight per CU, for the GEMMs that do not fill the chip with 256-row tiles)
+template <typename T, int TM>
+__global__ __launch_bounds__(256, TM == 256 ? 2 : 3) void conv1x1_mfma_kernel(const PwArgs a) {
+    constexpr int MI = TM / 128, NA = TM / 32;         // 32-row MFMA blocks per wave; 16-byte activation items per thread and K step
     extern __shared__ __attribute__((aligned(16))) char smem[];                // two stages of 40 KiB: two workgroups per CU
     constexpr int E16 = 16 / (int)sizeof(T);                                    // elements per 16-byte slot
     constexpr int KE = kKB / (int)sizeof(T);                                    // channels per K step
-    constexpr int kStage = (kTM + kTN) * kKB;
+    constexpr int kStage = (TM + kTN) * kKB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
 
     // cout tile fastest: the workgroups that share one pixel tile are neighbours in launch order (same XCD after the remap)
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int ct = bid % a.n_tiles;
-    const long long m0 = (long long)(bid / a.n_tiles) * kTM;
+    const long long m0 = (long long)(bid / a.n_tiles) * TM;
     const int co0 = ct * kTN;
 
     auto in_pixel = [&](long long m) __attribute__((always_inline)) -> long long {   // GEMM row -> pixel index of x (or -1)
@@ -91,10 +97,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
 
     // ---- staging: 8 activation items + 2 weight items of 16 B per thread and K step ----
     const int srow = tid >> 3, sslot = tid & 7;
-    const T* asrc[8];
-    bool aok[8];
+    const T* asrc[NA];
+    bool aok[NA];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NA; ++k) {
         const long long pix = in_pixel(m0 + srow + 32 * k);
         aok[k] = pix >= 0;
         asrc[k] = (const T*)a.x + (aok[k] ? pix : 0) * a.ldx + sslot * E16;      // clamped: loads are unconditional, zeroed afterwards
@@ -103,18 +109,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) wsrc[k] = (const T*)a.w + (size_t)(co0 + srow + 32 * k) * a.Cin + sslot * E16;
 
-    uint4 areg[8], wr0, wr1;            // the weight pair is named, not an array: hipcc parks a small array of uint4 in scratch here
+    uint4 areg[NA], wr0, wr1;            // the weight pair is named, not an array: hipcc parks a small array of uint4 in scratch here
     auto load_step = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) areg[k] = *(const uint4*)(asrc[k] + c0);
+        for (int k = 0; k < NA; ++k) areg[k] = *(const uint4*)(asrc[k] + c0);
         wr0 = *(const uint4*)(wsrc[0] + c0);
         wr1 = *(const uint4*)(wsrc[1] + c0);
     };
     auto store_step = [&](int stage) __attribute__((always_inline)) {
         char* a_lds = smem + stage * kStage;
-        char* w_lds = a_lds + kTM * kKB;
+        char* w_lds = a_lds + TM * kKB;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < NA; ++k) {
             // rows past the end of the GEMM are zeroed with a lane mask (a 128-bit select is lowered through scratch memory)
             const uint32_t m = aok[k] ? 0xffffffffu : 0u;
             *(uint4*)(a_lds + pw_off(srow + 32 * k, sslot)) = make_uint4(areg[k].x & m, areg[k].y & m, areg[k].z & m, areg[k].w & m);
@@ -124,9 +130,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
     };
 
     // accumulators TRANSPOSED (weights are the MFMA A operand): a lane owns 4 consecutive channels of one pixel per register quad
-    f32x16_t acc[2][2];
+    f32x16_t acc[MI][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -141,16 +147,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
     for (int c = 0; c < nsteps; ++c) {
         if (c + 1 < nsteps) load_step((c + 1) * KE);
         const char* a_lds = smem + (c & 1) * kStage;
-        const char* w_lds = a_lds + kTM * kKB;
+        const char* w_lds = a_lds + TM * kKB;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            uint4 af[2], bf[2];
+            uint4 af[MI], bf[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) af[mi] = *(const uint4*)(a_lds + pw_off(64 * wave + 32 * mi + l31, 2 * ks + lh));
+            for (int mi = 0; mi < MI; ++mi) af[mi] = *(const uint4*)(a_lds + pw_off(32 * MI * wave + 32 * mi + l31, 2 * ks + lh));
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) bf[ni] = *(const uint4*)(w_lds + pw_off(32 * ni + l31, 2 * ks + lh));
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) PwMma<T>::run(acc[mi][ni], bf[ni], af[mi]);      // D^T = W * X^T
         }
@@ -169,12 +175,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
         // one exposed round trip per tile), the result leaves as one 16-byte store -- half the memory instructions of the general
         // path below, same arithmetic in the same order (bias, + residual, activation, gate; one rounding at the end).
         if (os == 1) {
-            uint4 rq[2][2][2], eq[2][2][2];
-            bool okm[2];
-            const T* rp[2]; const T* ep[2]; T* yp[2];
+            uint4 rq[MI][2][2], eq[MI][2][2];
+            bool okm[MI];
+            const T* rp[MI]; const T* ep[MI]; T* yp[MI];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const long long m = m0 + 64 * wave + 32 * mi + l31;
+            for (int mi = 0; mi < MI; ++mi) {
+                const long long m = m0 + 32 * MI * wave + 32 * mi + l31;
                 okm[mi] = m < a.M;
                 const long long p = okm[mi] ? m : 0;
                 rp[mi] = a.res ? (const T*)a.res + p * a.ldres + co0 + 8 * lh : nullptr;
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
                     }
             }
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -231,8 +237,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const PwArgs a) {
         }
     }
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const long long m = m0 + 64 * wave + 32 * mi + l31;
+    for (int mi = 0; mi < MI; ++mi) {
+        const long long m = m0 + 32 * MI * wave + 32 * mi + l31;
         if (m >= a.M) continue;
         long long opix = m;
         int hc = 0, wc = 0;
@@ -635,18 +641,25 @@ extern "C" int wu_conv1x1_fwd(const void* x, int ldx, const void* w, const float
     a.Cin = Cin; a.Cout = Cout; a.act = act; a.egate_act = egate_act;
     a.M = (long long)N * Hc * Wc;
     a.n_tiles = Cout / kTN;
-    const long long grid = ((a.M + kTM - 1) / kTM) * a.n_tiles;
+    // tile: 128 rows (option 12 = 1: 256, the round-2 shape).  Same-box A/B in the GAN iteration: 28.12 ms with 256-row tiles, 27.62 with
+    // 128 rows only where 256-row tiles would not give every CU two workgroups, 27.31 with 128 rows everywhere -- the kernel's waves are
+    // parked 45-58 % of their cycles (SQ_WAIT_ANY, scratch/pmc_pw.sh), and three small workgroups per CU hide more of that than two large ones
+    const bool small = g_wu_opt[WU_OPT_PW_TILE] != 1;
+    const int tm = small ? 128 : 256;
+    const long long grid = ((a.M + tm - 1) / tm) * a.n_tiles;
     WU_REQUIRE(grid < (1ll << 31), "conv1x1_fwd: grid too large");
     hipStream_t s = (hipStream_t)stream;
     wu_prof_pre(WU_FAM_CONV1X1, s);
-    constexpr int kLds = 2 * (kTM + kTN) * kKB;              // 80 KiB
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<bf16_t, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + kTN) * kKB);
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<float, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + kTN) * kKB);
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<bf16_t, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + kTN) * kKB);
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<float, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + kTN) * kKB);
         attr_set = true;
     }
-    DISPATCH_T(dtype, hipLaunchKernelGGL(conv1x1_mfma_kernel<T>, dim3((unsigned)grid), dim3(256), kLds, s, a));
+    if (small) DISPATCH_T(dtype, hipLaunchKernelGGL((conv1x1_mfma_kernel<T, 128>), dim3((unsigned)grid), dim3(256), 2 * (128 + kTN) * kKB, s, a));
+    else DISPATCH_T(dtype, hipLaunchKernelGGL((conv1x1_mfma_kernel<T, 256>), dim3((unsigned)grid), dim3(256), 2 * (256 + kTN) * kKB, s, a));
     wu_prof_post(WU_FAM_CONV1X1, s, 2.0 * (double)a.M * Cin * Cout, ((double)a.M * (Cin + Cout * (residual ? 2 : 1)) + (double)Cin * Cout) * esz);
     WU_LAUNCH_CHECK("conv1x1_mfma");
     return 0;
