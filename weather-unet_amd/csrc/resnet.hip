@@ -67,16 +67,19 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
 // distinct over each group's rows of one parity.
 __device__ __forceinline__ int pw_off(int row, int slot) { return row * kKB + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-// TM = pixels per workgroup: 256 (two 40-KiB stages, 2 workgroups per CU) or 128 (two 24-KiB stages, 3 per CU: shorter chains of exposed
-// round trips per workgroup and more of them in flight per CU, for the GEMMs that do not fill the chip with 256-row tiles)
+// TM = pixels per workgroup: 256 (two 40-KiB LDS stages, 2 workgroups per CU), 128 (24 KiB, 3 per CU) or 64 (16 KiB, 4-5 per CU: the default --
+// shorter chains of exposed round trips per workgroup and more of them in flight per CU)
 template <typename T, int TM>
-__global__ __launch_bounds__(256, TM == 256 ? 2 : 3) void conv1x1_mfma_kernel(const PwArgs a) {
-    constexpr int MI = TM / 128, NA = TM / 32;         // 32-row MFMA blocks per wave; 16-byte activation items per thread and K step
+__global__ __launch_bounds__(256, TM == 256 ? 2 : (TM == 128 ? 3 : 4)) void conv1x1_mfma_kernel(const PwArgs a) {
+    // waves: WM along the pixels x WN along the couts (64 rows: 2 x 2, each wave one 32 x 32 block)
+    constexpr int WM = TM >= 128 ? 4 : 2, WN = 4 / WM, NI = 2 / WN;
+    constexpr int MI = TM / (32 * WM), NA = TM / 32;   // 32-row MFMA blocks per wave; 16-byte activation items per thread and K step
     extern __shared__ __attribute__((aligned(16))) char smem[];                // two stages of 40 KiB: two workgroups per CU
     constexpr int E16 = 16 / (int)sizeof(T);                                    // elements per 16-byte slot
     constexpr int KE = kKB / (int)sizeof(T);                                    // channels per K step
     constexpr int kStage = (TM + kTN) * kKB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave_ = tid >> 6;
+    const int wave = wave_ % WM, wn = wave_ / WM;          // pixel block / cout block of this wave
     const int l31 = lane & 31, lh = lane >> 5;
 
     // cout tile fastest: the workgroups that share one pixel tile are neighbours in launch order (same XCD after the remap)
@@ -130,11 +133,11 @@ __global__ __launch_bounds__(256, TM == 256 ? 2 : 3) void conv1x1_mfma_kernel(co
     };
 
     // accumulators TRANSPOSED (weights are the MFMA A operand): a lane owns 4 consecutive channels of one pixel per register quad
-    f32x16_t acc[MI][2];
+    f32x16_t acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
@@ -150,15 +153,15 @@ __global__ __launch_bounds__(256, TM == 256 ? 2 : 3) void conv1x1_mfma_kernel(co
         const char* w_lds = a_lds + TM * kKB;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            uint4 af[MI], bf[2];
+            uint4 af[MI], bf[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) af[mi] = *(const uint4*)(a_lds + pw_off(32 * MI * wave + 32 * mi + l31, 2 * ks + lh));
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bf[ni] = *(const uint4*)(w_lds + pw_off(32 * ni + l31, 2 * ks + lh));
+            for (int ni = 0; ni < NI; ++ni) bf[ni] = *(const uint4*)(w_lds + pw_off(32 * (NI * wn + ni) + l31, 2 * ks + lh));
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) PwMma<T>::run(acc[mi][ni], bf[ni], af[mi]);      // D^T = W * X^T
+                for (int ni = 0; ni < NI; ++ni) PwMma<T>::run(acc[mi][ni], bf[ni], af[mi]);      // D^T = W * X^T
         }
         if (c + 1 < nsteps) {
             store_step((c + 1) & 1);
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256, TM == 256 ? 2 : 3) void conv1x1_mfma_kernel(co
         // one exposed round trip per tile), the result leaves as one 16-byte store -- half the memory instructions of the general
         // path below, same arithmetic in the same order (bias, + residual, activation, gate; one rounding at the end).
         if (os == 1) {
-            uint4 rq[MI][2][2], eq[MI][2][2];
+            uint4 rq[MI][NI][2], eq[MI][NI][2];
             bool okm[MI];
             const T* rp[MI]; const T* ep[MI]; T* yp[MI];
 #pragma unroll
@@ -187,24 +190,24 @@ __global__ __launch_bounds__(256, TM == 256 ? 2 : 3) void conv1x1_mfma_kernel(co
                 ep[mi] = a.egate ? (const T*)a.egate + p * a.ldegate + co0 + 8 * lh : nullptr;
                 yp[mi] = (T*)a.y + p * a.ldy + co0 + 8 * lh;
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {
-                        if (a.res) rq[mi][ni][gp] = *(const uint4*)(rp[mi] + 32 * ni + 16 * gp);
-                        if (a.egate) eq[mi][ni][gp] = *(const uint4*)(ep[mi] + 32 * ni + 16 * gp);
+                        if (a.res) rq[mi][ni][gp] = *(const uint4*)(rp[mi] + 32 * (NI * wn + ni) + 16 * gp);
+                        if (a.egate) eq[mi][ni][gp] = *(const uint4*)(ep[mi] + 32 * (NI * wn + ni) + 16 * gp);
                     }
             }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {
                         float lo[4], hi[4];
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             const int g = 2 * gp + e;
-                            const float4 bv = a.bias ? *(const float4*)(a.bias + co0 + 32 * ni + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            const float4 bv = a.bias ? *(const float4*)(a.bias + co0 + 32 * (NI * wn + ni) + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
                             float* d = e ? hi : lo;
                             d[0] = acc[mi][ni][4 * g + 0] + bv.x; d[1] = acc[mi][ni][4 * g + 1] + bv.y;
                             d[2] = acc[mi][ni][4 * g + 2] + bv.z; d[3] = acc[mi][ni][4 * g + 3] + bv.w;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256, TM == 256 ? 2 : 3) void conv1x1_mfma_kernel(co
 #pragma unroll
                             for (int e = 0; e < 8; ++e) o[e] = act_gate(o[e], ev[e], a.egate_act);
                         }
-                        if (okm[mi]) *(uint4*)(yp[mi] + 32 * ni + 16 * gp) = pack16<T>(o);
+                        if (okm[mi]) *(uint4*)(yp[mi] + 32 * (NI * wn + ni) + 16 * gp) = pack16<T>(o);
                     }
             return;
         }
@@ -250,10 +253,10 @@ __global__ __launch_bounds__(256, TM == 256 ? 2 : 3) void conv1x1_mfma_kernel(co
             opix = (n * a.Hout + (long long)hc * os) * a.Wout + (long long)wc * os;
         }
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int co = co0 + 32 * ni + 8 * g + 4 * lh;
+                const int co = co0 + 32 * (NI * wn + ni) + 8 * g + 4 * lh;
                 float v[4];
                 const float4 bv = a.bias ? *(const float4*)(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
                 v[0] = acc[mi][ni][4 * g + 0] + bv.x; v[1] = acc[mi][ni][4 * g + 1] + bv.y;
@@ -641,24 +644,25 @@ extern "C" int wu_conv1x1_fwd(const void* x, int ldx, const void* w, const float
     a.Cin = Cin; a.Cout = Cout; a.act = act; a.egate_act = egate_act;
     a.M = (long long)N * Hc * Wc;
     a.n_tiles = Cout / kTN;
-    // tile: 128 rows (option 12 = 1: 256, the round-2 shape).  Same-box A/B in the GAN iteration: 28.12 ms with 256-row tiles, 27.62 with
-    // 128 rows only where 256-row tiles would not give every CU two workgroups, 27.31 with 128 rows everywhere -- the kernel's waves are
-    // parked 45-58 % of their cycles (SQ_WAIT_ANY, scratch/pmc_pw.sh), and three small workgroups per CU hide more of that than two large ones
-    const bool small = g_wu_opt[WU_OPT_PW_TILE] != 1;
-    const int tm = small ? 128 : 256;
+    // pixel tile: 64 rows (option 12: 1 = 256 rows, the round-2 shape; 2 = 128 rows).  Same-box A/B of the whole GAN iteration: 28.12 ms
+    // with 256-row tiles, 27.31-27.55 with 128, 27.13 with 64 -- the kernel's waves are parked 45-58 % of their cycles (SQ_WAIT_ANY,
+    // scratch/pmc_pw.sh) behind a short chain of fetch / barrier / epilogue round trips, and five small workgroups per CU hide more
+    // of that than two large ones; the weights they re-read come from L2
+    const int tm = g_wu_opt[WU_OPT_PW_TILE] == 1 ? 256 : (g_wu_opt[WU_OPT_PW_TILE] == 2 ? 128 : 64);
     const long long grid = ((a.M + tm - 1) / tm) * a.n_tiles;
     WU_REQUIRE(grid < (1ll << 31), "conv1x1_fwd: grid too large");
     hipStream_t s = (hipStream_t)stream;
     wu_prof_pre(WU_FAM_CONV1X1, s);
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<bf16_t, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + kTN) * kKB);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<float, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + kTN) * kKB);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<bf16_t, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + kTN) * kKB);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<float, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + kTN) * kKB);
+#define WU_PW_ATTR(TM_) (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<bf16_t, TM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + kTN) * kKB); \
+                        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<float, TM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + kTN) * kKB)
+        WU_PW_ATTR(256); WU_PW_ATTR(128); WU_PW_ATTR(64);
+#undef WU_PW_ATTR
         attr_set = true;
     }
-    if (small) DISPATCH_T(dtype, hipLaunchKernelGGL((conv1x1_mfma_kernel<T, 128>), dim3((unsigned)grid), dim3(256), 2 * (128 + kTN) * kKB, s, a));
+    if (tm == 64) DISPATCH_T(dtype, hipLaunchKernelGGL((conv1x1_mfma_kernel<T, 64>), dim3((unsigned)grid), dim3(256), 2 * (64 + kTN) * kKB, s, a));
+    else if (tm == 128) DISPATCH_T(dtype, hipLaunchKernelGGL((conv1x1_mfma_kernel<T, 128>), dim3((unsigned)grid), dim3(256), 2 * (128 + kTN) * kKB, s, a));
     else DISPATCH_T(dtype, hipLaunchKernelGGL((conv1x1_mfma_kernel<T, 256>), dim3((unsigned)grid), dim3(256), 2 * (256 + kTN) * kKB, s, a));
     wu_prof_post(WU_FAM_CONV1X1, s, 2.0 * (double)a.M * Cin * Cout, ((double)a.M * (Cin + Cout * (residual ? 2 : 1)) + (double)Cin * Cout) * esz);
     WU_LAUNCH_CHECK("conv1x1_mfma");
