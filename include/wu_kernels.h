@@ -88,6 +88,16 @@ int wu_spectral_norm_fwd(const float* w, int rows, int cols, float* u, float* v,
                          float* sigma_out, float* w_eff, float* scratch, void* stream);
 int wu_spectral_norm_bwd(const float* g, const float* w, const float* u, const float* v, const float* sigma,
                          float* dw, int rows, int cols, float* scratch, void* stream);
+/* The same for n <= 16 weights per call -- all ten SN layers of SNDisc (disc.py:11-24: eight convs, `l`, `embed`) in 5 launches forward
+ * and 2 backward instead of 5 n / 2 n.  Arrays of n entries in HOST memory (read during the call), entry i as in the single-weight
+ * call; results are bit-identical to n single calls.  u_save / v_save (the arrays and their entries may be NULL): copies of the u, v
+ * that define sigma_out[i], for the backward pass (the buffers advance on the next forward). */
+int wu_spectral_norm_fwd_multi(int n, const float* const* w, const int* rows, const int* cols, float* const* u, float* const* v,
+                               int power_iter, float eps, float* const* sigma_out, float* const* w_eff, float* const* scratch,
+                               float* const* u_save, float* const* v_save, void* stream);
+int wu_spectral_norm_bwd_multi(int n, const float* const* g, const float* const* w, const float* const* u, const float* const* v,
+                               const float* const* sigma, float* const* dw, const int* rows, const int* cols, float* const* scratch,
+                               void* stream);
 
 /* ---- conv3x3, pad 1, MFMA implicit GEMM -----------------------------------------------------
  * y = act(conv3x3(x, w) + bias)   replaces nn.Conv2d(cin,cout,3,padding=1[,stride=2]) + ReLU /

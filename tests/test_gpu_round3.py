@@ -547,3 +547,79 @@ def test_sndisc_bf16_gradients_vs_emulating_oracle(size, batch):
     cs_x = _cos(xd.grad, xr.grad)
     print(f"   SNDisc bf16 vs emulation, input gradient cos {cs_x:.6f}")
     assert worst >= 0.999 and cs_x >= 0.999
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# batched spectral normalisation (wu_spectral_norm_{fwd,bwd}_multi): the ten SN layers of SNDisc in one call
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("power_iter", [True, False])
+def test_spectral_norm_multi_is_bitwise_the_single_weight_path(power_iter):
+    """SNDisc's ten weight shapes (disc.py:11-24): W/sigma, the advanced u / v buffers and the weight gradients of the batched call
+    equal ten single-weight calls bit for bit."""
+    from wu import functional as WF
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    shapes = [(3, 3, 3, 3), (64, 3, 3, 3), (64, 64, 3, 3), (128, 64, 3, 3), (128, 128, 3, 3), (256, 128, 3, 3), (256, 256, 3, 3),
+              (512, 256, 3, 3), (1, 512), (512, 5)]
+    ws = [(torch.randn(s, generator=g) * 0.1).to(dev) for s in shapes]
+    rows = [s[0] for s in shapes]
+    cols = [int(np.prod(s[1:])) for s in shapes]
+    us = [F.normalize(torch.randn(r, generator=g), dim=0).to(dev) for r in rows]
+    vs = [F.normalize(torch.randn(c, generator=g), dim=0).to(dev) for c in cols]
+    gs = [torch.randn(s, generator=g).to(dev) for s in shapes]
+
+    def run(multi):
+        w = [t.clone().requires_grad_(True) for t in ws]
+        u, v = [t.clone() for t in us], [t.clone() for t in vs]
+        if multi:
+            out = WF.spectral_normalize_multi(w, u, v, power_iter, 1e-12)
+        else:
+            out = [WF.spectral_normalize(wi, ui, vi, power_iter, 1e-12) for wi, ui, vi in zip(w, u, v)]
+        torch.autograd.backward(list(out), gs)
+        return [o.detach() for o in out], u, v, [t.grad for t in w]
+
+    a, b = run(False), run(True)
+    for name, xs, ys in zip(("w_eff", "u", "v", "dw"), a, b):
+        for i, (x, y) in enumerate(zip(xs, ys)):
+            assert torch.equal(x, y), f"{name}[{i}] {shapes[i]} differs: max {(x - y).abs().max().item():.3e}"
+    # and against torch's own arithmetic (fp32 round-off of a differently ordered dot product)
+    for i in range(len(ws)):
+        wm = ws[i].reshape(rows[i], -1)
+        if power_iter:
+            v_ref = F.normalize(wm.t() @ us[i], dim=0, eps=1e-12)
+            u_ref = F.normalize(wm @ v_ref, dim=0, eps=1e-12)
+        else:
+            u_ref, v_ref = us[i], vs[i]
+        sigma = torch.dot(u_ref, wm @ v_ref)
+        assert torch.allclose(b[0][i], ws[i] / sigma, rtol=2e-5, atol=1e-7)
+        assert torch.allclose(b[1][i], u_ref, rtol=1e-4, atol=1e-6) and torch.allclose(b[2][i], v_ref, rtol=1e-4, atol=1e-6)
+
+
+def test_sndisc_batched_normalisation_matches_per_layer_path():
+    """SNDisc.forward (one batched normalisation, SNLinear heads) against the same module with every layer normalising its own
+    weight (the pre-batching path, forced by handing the layers no weights): outputs, advanced buffers and parameter gradients
+    bit for bit, in training mode over two consecutive forwards (two power iterations) and in eval mode."""
+    import disc
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    Da = disc.SNDisc(5, precision="bf16").to(dev)
+    Db = disc.SNDisc(5, precision="bf16").to(dev)
+    Db.load_state_dict(Da.state_dict())
+    Db._normalize_weights = lambda: []
+    g = torch.Generator(device="cpu").manual_seed(6)
+    c = torch.softmax(torch.randn(4, 5, generator=g), dim=1).to(dev)
+    for mode in ("train", "train", "eval"):
+        x = (torch.rand((4, 3, 64, 64), generator=g) * 2 - 1).to(dev)
+        outs = []
+        for D in (Da, Db):
+            D.train(mode == "train")
+            D.zero_grad(set_to_none=True)
+            o = D(x, c)
+            (o[0].sum() + o[4].float().mean()).backward()
+            outs.append(o)
+        for ta, tb in zip(outs[0], outs[1]):
+            assert torch.equal(ta, tb)
+        for (ka, ta), (kb, tb) in zip(Da.state_dict().items(), Db.state_dict().items()):
+            assert ka == kb and torch.equal(ta, tb), ka
+        for (ka, pa), (_, pb) in zip(Da.named_parameters(), Db.named_parameters()):
+            assert pa.grad is not None and torch.equal(pa.grad, pb.grad), ka

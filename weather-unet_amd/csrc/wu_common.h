@@ -170,4 +170,4 @@ __host__ __device__ __forceinline__ uint64_t wu_rand4(uint64_t seed, uint64_t gr
     return wu_mix64(seed * 0x9E3779B97F4A7C15ull + group + 0x632BE59BD9B4E019ull);
 }
 
-static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

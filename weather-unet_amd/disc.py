@@ -3,17 +3,25 @@
 4 x (SN-conv3x3 s1 -> SN-conv3x3 s2 -> LeakyReLU 0.2) -> global SUM pool -> SN-Linear(512,1) +
 <SN-Linear(nc,512)(c), feat>.  ``forward(x, c) -> [out(N,1), c1, c2, c3, c4]``; 40 state-dict keys
 (10 SN layers x bias / weight_orig / weight_u / weight_v).  The convs reuse the generator's HIP kernels
-(stride-1/2 MFMA implicit GEMM, LeakyReLU epilogue); the two linear heads are (N,512) GEMVs kept in torch.
+(stride-1/2 MFMA implicit GEMM, LeakyReLU epilogue); the two linear heads are (N,512) GEMVs kept in torch.  All ten spectral
+normalisations of a forward (one power iteration each in training mode, as torch's hooks do) run as ONE batched call before the convs.
 The feature maps c1..c4 are returned as NHWC-strided tensors of the compute dtype (logical NCHW shape).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
 
-from nets import sn_double_conv
+from nets import SNLinear, sn_double_conv
 from utils import ConditionalNorm  # noqa: F401  (imported by the reference, disc.py:5)
 from wu import functional as WF
+from wu import kernels as K
 from wu.layout import precision_code, require_cuda
+
+
+# one batched spectral normalisation per forward (default) or one per layer (A/B switch, WU_SN_BATCHED=0)
+BATCHED_SPECTRAL_NORM = os.environ.get("WU_SN_BATCHED", "1") == "1"
 
 
 class SNDisc(nn.Module):
@@ -34,10 +42,10 @@ class SNDisc(nn.Module):
             for j in range(2):
                 nn.init.xavier_uniform_(getattr(self, 'conv{}'.format(i))[j].weight_orig, np.sqrt(2))
 
-        self.l = nn.utils.spectral_norm(nn.Linear(512, 1))
+        self.l = SNLinear(512, 1)                                            # nn.utils.spectral_norm(nn.Linear(512, 1)), disc.py:21
         nn.init.xavier_uniform_(self.l.weight_orig)
 
-        self.embed = nn.utils.spectral_norm(nn.Linear(num_classes, 512, bias=True))
+        self.embed = SNLinear(num_classes, 512, bias=True)                   # disc.py:23
         nn.init.xavier_uniform_(self.embed.weight_orig)
         self.set_precision(precision)
 
@@ -48,8 +56,42 @@ class SNDisc(nn.Module):
             m.set_precision(precision)
         return self
 
+    def sn_layers(self):
+        """The ten spectrally normalised layers in forward order."""
+        return [m for i in range(1, 5) for m in getattr(self, 'conv{}'.format(i))[:2]] + [self.l, self.embed]
+
+    def _normalize_weights(self):
+        """W/sigma of all ten SN layers in one batched call (what torch's ten forward pre-hooks compute one by one: a power
+        iteration per layer in training mode, buffers updated in place), handed to the layers for their next forward; the packed
+        MFMA operands of the six wide convs are rebuilt in one launch as well."""
+        layers = self.sn_layers()
+        if not BATCHED_SPECTRAL_NORM or len({m.training for m in layers}) != 1 or len({m.eps for m in layers}) != 1 or not layers[0].weight_orig.is_cuda:
+            return []                                        # mixed modes / CPU: every layer normalises its own weight
+        train = layers[0].training
+        w_eff = WF.spectral_normalize_multi([m.weight_orig for m in layers], [m.weight_u for m in layers], [m.weight_v for m in layers],
+                                            train, layers[0].eps)
+        for m, w in zip(layers, w_eff):
+            if train:
+                m._sn_generation += 1
+            m._w_eff_next = w
+        code = precision_code(self.precision)
+        todo = [(m, w) for m, w in zip(layers[:8], w_eff[:8]) if m.in_channels != 3 and m._packed.stale(w, code, m.weight_ident())]
+        if todo:
+            for (m, w), (wf, wd) in zip(todo, K.pack_conv3x3_multi([w for _, w in todo], code)):
+                m._packed.w_fwd, m._packed.w_dgrad = wf, wd
+                m._packed.key = m._packed.make_key(w, code, m.weight_ident())
+        return layers
+
     def forward(self, x, c=None):
         require_cuda(x, "SNDisc")
+        pending = self._normalize_weights()
+        try:
+            return self._forward(x, c)
+        finally:
+            for m in pending:                                # an exception mid-way must not leave a weight behind for a later call
+                m._w_eff_next = None
+
+    def _forward(self, x, c):
         c1 = self.conv1(x)                                   # :28
         c2 = self.conv2(c1)                                  # :29
         c3 = self.conv3(c2)                                  # :30

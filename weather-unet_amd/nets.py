@@ -95,6 +95,7 @@ class SNConv3x3(_Conv3x3Base):
         self.register_buffer("weight_u", u)
         self.register_buffer("weight_v", v)
         self._sn_generation = 0        # bumped whenever a power iteration rewrites weight_u / weight_v through raw pointers
+        self._w_eff_next = None        # W/sigma handed in by the owner's batched normalisation (disc.SNDisc.forward), used once
 
     @property
     def weight(self):
@@ -102,6 +103,10 @@ class SNConv3x3(_Conv3x3Base):
         return spectral_normalize(self.weight_orig, self.weight_u, self.weight_v, False, self.eps)
 
     def effective_weight(self):
+        w = self._w_eff_next
+        if w is not None:              # normalised by the owner together with its other SN layers (one batched call)
+            self._w_eff_next = None
+            return w
         if self.training:
             self._sn_generation += 1
         return spectral_normalize(self.weight_orig, self.weight_u, self.weight_v, self.training, self.eps)
@@ -129,6 +134,46 @@ def spectral_normalize(weight_orig, u, v, do_power_iteration, eps=1e-12):
         u, v = u.clone(), v.clone()
     sigma = torch.dot(u, torch.mv(w_mat, v))
     return weight_orig / sigma
+
+
+class SNLinear(nn.Module):
+    """nn.utils.spectral_norm(nn.Linear(cin, cout)) (reference disc.py:21-24, the heads ``l`` and ``embed``) with the state-dict
+    keys torch gives it -- ``bias``, ``weight_orig``, ``weight_u``, ``weight_v`` -- and the same RNG draws at construction
+    (nn.Linear's init, then u ~ N(0,1)^cout and v ~ N(0,1)^cin, normalised), on the HIP spectral-norm kernels: torch's hook is ~25
+    launches per forward and layer, this shares the network's one batched normalisation (SNDisc.forward)."""
+
+    def __init__(self, in_features, out_features, bias=True, eps=1e-12):
+        super().__init__()
+        lin = nn.Linear(in_features, out_features, bias=bias)
+        self.in_features, self.out_features, self.eps = in_features, out_features, eps
+        self.bias = lin.bias
+        self.weight_orig = nn.Parameter(lin.weight.detach())
+        with torch.no_grad():
+            u = F_.normalize(self.weight_orig.new_empty(out_features).normal_(0, 1), dim=0, eps=eps)
+            v = F_.normalize(self.weight_orig.new_empty(in_features).normal_(0, 1), dim=0, eps=eps)
+        self.register_buffer("weight_u", u)
+        self.register_buffer("weight_v", v)
+        self._sn_generation = 0
+        self._w_eff_next = None
+
+    @property
+    def weight(self):
+        return spectral_normalize(self.weight_orig, self.weight_u, self.weight_v, False, self.eps)
+
+    def effective_weight(self):
+        w = self._w_eff_next
+        if w is not None:
+            self._w_eff_next = None
+            return w
+        if self.training:
+            self._sn_generation += 1
+        return spectral_normalize(self.weight_orig, self.weight_u, self.weight_v, self.training, self.eps)
+
+    def forward(self, x):
+        return F_.linear(x, self.effective_weight(), self.bias)
+
+    def extra_repr(self):
+        return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}"
 
 
 class _FusedSequential(nn.Sequential):

@@ -34,6 +34,8 @@ SIGNATURES = {
     "wu_spectral_norm_scratch_floats": (SZ, [I, I]),
     "wu_spectral_norm_fwd": (I, [P, I, I, P, P, I, F, P, P, P, P]),
     "wu_spectral_norm_bwd": (I, [P, P, P, P, P, P, I, I, P, P]),
+    "wu_spectral_norm_fwd_multi": (I, [I, P, P, P, P, P, I, F, P, P, P, P, P, P]),
+    "wu_spectral_norm_bwd_multi": (I, [I, P, P, P, P, P, P, P, P, P, P]),
     "wu_pack_conv3x3": (I, [P, P, P, I, I, P, I, P]),
     "wu_pack_conv3x3_multi": (I, [I, P, P, P, P, P, I, P]),
     "wu_conv3x3_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P, I, I, P, I, I, I, P]),

@@ -444,6 +444,92 @@ def spectral_normalize(weight_orig, u, v, do_power_iteration, eps=1e-12):
     return SpectralNormFn.apply(weight_orig, u, v, do_power_iteration, eps)
 
 
+_SN_SCRATCH = {}
+
+
+def _sn_scratch_floats(rows, cols):
+    k = (rows, cols)
+    n = _SN_SCRATCH.get(k)
+    if n is None:
+        n = _SN_SCRATCH[k] = int(_lib.load().wu_spectral_norm_scratch_floats(rows, cols))
+    return n
+
+
+class SpectralNormMultiFn(Function):
+    """SpectralNormFn for the n <= 16 weights of one network in ONE call (wu_spectral_norm_fwd_multi: 5 launches forward, 2 backward,
+    whatever n): SNDisc normalises ten weights per forward (disc.py:11-24) and 50 + 20 launches of a few microseconds each were a
+    quarter of its GPU time at B = 32.  Same per-weight arithmetic, bit-identical results.  One slab holds every scratch area,
+    sigma pair and the copies of u / v the backward needs (written by the kernels: no clone launches)."""
+
+    @staticmethod
+    def forward(ctx, do_power_iteration, eps, n, *tensors):
+        import ctypes
+        ws, us, vs = tensors[:n], tensors[n:2 * n], tensors[2 * n:3 * n]
+        require_cuda(ws[0], "spectral_norm")
+        wd = []
+        for w in ws:
+            w = w.detach()
+            wd.append(w if w.is_contiguous() else w.contiguous())
+        rows = [w.shape[0] for w in wd]
+        cols = [w.numel() // r for w, r in zip(wd, rows)]
+        need_bwd = any(ctx.needs_input_grad[3:3 + n])
+        # slab layout (floats): per weight [scratch | sigma(2, padded to 4) | u_save | v_save], every area 16-byte aligned
+        off, areas = 0, []
+        for r, c in zip(rows, cols):
+            a = {"scratch": off}
+            off += (_sn_scratch_floats(r, c) + 3) // 4 * 4
+            a["sigma"] = off
+            off += 4
+            if need_bwd:
+                a["u"] = off
+                off += (r + 3) // 4 * 4
+                a["v"] = off
+                off += (c + 3) // 4 * 4
+            areas.append(a)
+        dev = wd[0].device
+        slab = torch.empty(off, dtype=torch.float32, device=dev)
+        base = slab.data_ptr()
+        w_eff = [torch.empty_like(w) for w in wd]
+        P, I = ctypes.c_void_p * n, ctypes.c_int * n
+        at = lambda key: P(*[base + 4 * a[key] for a in areas])  # noqa: E731
+        _lib.call("wu_spectral_norm_fwd_multi", n, P(*[w.data_ptr() for w in wd]), I(*rows), I(*cols), P(*[u.data_ptr() for u in us]),
+                  P(*[v.data_ptr() for v in vs]), 1 if do_power_iteration else 0, float(eps), at("sigma"), P(*[w.data_ptr() for w in w_eff]),
+                  at("scratch"), at("u") if need_bwd else None, at("v") if need_bwd else None, stream_ptr())
+        if need_bwd:
+            ctx.save_for_backward(slab, *wd)
+            ctx.areas, ctx.dims = areas, (rows, cols)
+        return tuple(w_eff)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        import ctypes
+        slab, *wd = ctx.saved_tensors
+        rows, cols = ctx.dims
+        n = len(wd)
+        idx = [i for i in range(n) if gs[i] is not None and ctx.needs_input_grad[3 + i]]
+        dws = [None] * n
+        if idx:
+            m = len(idx)
+            g = [gs[i].float().contiguous() for i in idx]
+            for i in idx:
+                dws[i] = torch.empty_like(wd[i])
+            base = slab.data_ptr()
+            P, I = ctypes.c_void_p * m, ctypes.c_int * m
+            at = lambda key: P(*[base + 4 * ctx.areas[i][key] for i in idx])  # noqa: E731
+            # the forward's scratch areas are free again: they hold the <G, W> partials now
+            _lib.call("wu_spectral_norm_bwd_multi", m, P(*[t.data_ptr() for t in g]), P(*[wd[i].data_ptr() for i in idx]), at("u"), at("v"),
+                      at("sigma"), P(*[dws[i].data_ptr() for i in idx]), I(*[rows[i] for i in idx]), I(*[cols[i] for i in idx]),
+                      at("scratch"), stream_ptr())
+        return (None, None, None) + tuple(dws) + (None,) * (2 * n)
+
+
+def spectral_normalize_multi(weights, us, vs, do_power_iteration, eps=1e-12):
+    """[W_i / sigma_i] for lists of weight_orig / weight_u / weight_v (at most 16): see SpectralNormMultiFn."""
+    n = len(weights)
+    assert 0 < n <= 16 and len(us) == n and len(vs) == n
+    return SpectralNormMultiFn.apply(do_power_iteration, eps, n, *weights, *us, *vs)
+
+
 # ----------------------------------------------------------------------------------------------
 # AdaIN style statistics: l1(y).view(N, C, 4) -> (std, mean)                    utils.py:41-48
 # ----------------------------------------------------------------------------------------------

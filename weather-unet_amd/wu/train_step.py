@@ -24,6 +24,8 @@ Differences from the reference loop, all numerically neutral:
     gradients that g_loss.backward() deposits (and the next d_opt.zero_grad() discards, t_cls_train.py:291) are
     not all-reduced.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -31,6 +33,10 @@ import ops
 from cunet import Conditional_UNet
 from disc import SNDisc
 from wu.ddp import GradBucketReducer, broadcast_buffers, is_distributed, ready_order
+
+
+# update_inference: the discriminator's pass over the fake batch on a second stream, beside the estimator's (A/B switch)
+OVERLAP_D_WITH_ESTIMATOR = os.environ.get("WU_GAN_OVERLAP", "1") == "1"
 
 
 class StandInEstimator(nn.Module):
@@ -82,6 +88,12 @@ class WeatherTransferStep:
             self.d_red = GradBucketReducer(list(self.discriminator.parameters()), bucket_mb=12.0)
             broadcast_buffers(self.discriminator)      # SN weight_u / weight_v identical on every rank
 
+    def _d_stream(self, dev):
+        """The probed second stream of the fused U-Net graph (a stream that really runs beside the current one: HIP maps streams
+        onto a few hardware queues, unet_graph._side_stream).  G's backward, its other user, starts after both passes have ended."""
+        from wu.unet_graph import _side_stream
+        return _side_stream(dev)
+
     def estimator(self, x):
         """``self.estimator`` of the scripts: softmax head in t_cls_train (:174-178), raw in t_est_train."""
         y = self.estimator_(x)
@@ -127,19 +139,33 @@ class WeatherTransferStep:
         d_params = list(self.discriminator.parameters())
         for p in d_params:
             p.requires_grad_(False)
+        if self.cross_ent and r_labels_ is None:
+            raise ValueError("update_inference: --cross_ent needs the class indices r_labels_ (t_cls_train.py:434-438)")
+        # D(fake) and estimator(fake) both hang off fake_out and nothing else: D runs on a second stream beside the estimator
+        # (autograd replays each node on the stream of its forward, so the two data-gradient chains overlap in backward too).
+        # Same kernels, same numbers: the sum into fake_out's gradient follows graph order, not completion order.
+        side = self._d_stream(images.device) if OVERLAP_D_WITH_ESTIMATOR and images.is_cuda else None
         try:
             fake_out = self.inference(images, r_labels)                                  # :242
-            fake_d_out = self.discriminator(fake_out, r_labels)[0]                       # :243-244
+            if side is not None:
+                main = torch.cuda.current_stream(images.device)
+                side.wait_stream(main)
+                fake_out.record_stream(side)
+                with torch.cuda.stream(side):
+                    fake_d_out = self.discriminator(fake_out, r_labels)[0]               # :243-244
+                fake_d_out.record_stream(main)
+            else:
+                fake_d_out = self.discriminator(fake_out, r_labels)[0]                   # :243-244
         finally:
             for p in d_params:
                 p.requires_grad_(True)
         if self.cross_ent:
-            if r_labels_ is None:
-                raise ValueError("update_inference: --cross_ent needs the class indices r_labels_ (t_cls_train.py:434-438)")
             fake_c_out = self.estimator_(fake_out)                                       # :248 last layer is not softmax
         else:
             fake_c_out = self.estimator(fake_out)                                        # :250
             r_labels_ = r_labels                                                         # :251
+        if side is not None:
+            main.wait_stream(side)
         g_loss_adv = ops.gen_hinge(fake_d_out)                                           # :254 adversarial
         g_loss_w = ops.pred_loss(fake_c_out, r_labels_, one_hot=self.cross_ent)          # :256 weather prediction
         diff = torch.mean(torch.abs(fake_out - images), [1, 2, 3])
