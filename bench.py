@@ -211,18 +211,21 @@ def main():
         families += [_lib.FAM_CONV_S2, _lib.FAM_WGRAD_S2, _lib.FAM_CONV1X1]
     do_roof = (not a.no_roofline) and rank == 0
     pre_stats = None
-    if do_roof and gan is not None:
-        # GAN workloads launch ~550 instrumented kernels per iteration and the hipEvent pair around each costs ~6 us of stream time
-        # (3.5 ms of a 31 ms iteration).  One extra, untimed, fully instrumented iteration finds the dominant family and gives the
-        # other families' figures; the timed region then brackets the dominant family only.
-        _lib.prof_begin(families, 1024 + 64)
+    families_timed = families
+    if not a.no_roofline and not a.fwd_only:
+        # The hipEvent pair around an instrumented launch costs ~5 us of stream time: 39 pairs are 0.19 ms of the 8.5 ms U-Net step
+        # (same-box A/B against --no-roofline, profiles/r03_roofline_overhead.txt), ~550 pairs 3.5 ms of a 31 ms GAN iteration.  One
+        # extra, untimed, fully instrumented iteration finds the dominant family and gives the other families' figures; the timed
+        # region then brackets the dominant family only (every one of its launches).  Every rank runs the extra iteration (it
+        # contains the gradient all-reduce); rank 0 alone instruments it.
+        if do_roof:
+            _lib.prof_begin(families, 1024 + 64)
         step()
         torch.cuda.synchronize()
-        pre_stats = {f: _lib.prof_query(f) for f in families}
-        _lib.prof_end()
-        families_timed = [max(pre_stats, key=lambda f: pre_stats[f]["ms"])]
-    else:
-        families_timed = families
+        if do_roof:
+            pre_stats = {f: _lib.prof_query(f) for f in families}
+            _lib.prof_end()
+            families_timed = [max(pre_stats, key=lambda f: pre_stats[f]["ms"])]
     if do_roof:
         _lib.prof_begin(families_timed, (64 if gan is None else 1024) * a.steps + 64)
     barrier()

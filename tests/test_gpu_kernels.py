@@ -177,7 +177,9 @@ def test_conv3x3_gated_abi_paths(p, act):
 
 @pytest.mark.parametrize("p", DTYPES)
 @pytest.mark.parametrize("cfg", [(2, 64, 16, 24, 1, 1, False), (2, 64, 17, 19, 2, 2, False), (2, 3, 12, 20, 1, 0, True),
-                                 (2, 64, 40, 72, 2, 2, False), (1, 64, 34, 130, 2, 0, False)])
+                                 (2, 64, 40, 72, 2, 2, False), (1, 64, 34, 130, 2, 0, False),
+                                 # the LDS-tiled image-layout 3 -> 3 conv: ragged tiles (W % 4 != 0), several tiles, an activation
+                                 (2, 3, 37, 131, 1, 0, True), (1, 3, 64, 128, 1, 2, True), (3, 3, 16, 64, 1, 1, True)])
 def test_conv3x3_c3(p, cfg):
     """3-input-channel conv read from the NCHW fp32 image (cunet.py:45, disc.py:28): fwd, wgrad, dgrad."""
     from wu import functional as WF

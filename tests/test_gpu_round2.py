@@ -488,8 +488,11 @@ def test_three_step_trajectory_fused_vs_foreach_adam():
     assert la[0] == lb[0]
     assert all(abs(a - b) <= 1e-5 * max(1.0, abs(b)) for a, b in zip(la, lb)), (la, lb)
     assert la[2] < la[0]
-    # beta1 = 0: an element's step is lr * g / (|g| + eps), ill-conditioned where g ~ 0, so single elements may differ by a fraction
-    # of a step between the two optimizer implementations; the bulk must agree to rounding
+    # beta1 = 0: an element's step is lr * g / (|g| + eps) -- a SIGN function of g up to eps, ill-conditioned where g ~ 0: a single
+    # element whose tiny gradient rounds to the other sign in one of the two implementations moves a full step the other way
+    # (2 lr apart).  Step 1 sees identical gradients; the two implementations' last-bit differences then perturb the gradients of steps
+    # 2 and 3, so the worst case is two opposite steps = 4 lr = 8e-3 (observed 1.2e-3 ... 5.0e-3 on single elements, depending on the
+    # build); the bulk must agree to rounding (mean)
     for k in pa:
         d = (pa[k].float() - pb[k].float()).abs()
-        assert d.max().item() <= 1.5e-3 and d.mean().item() <= 2e-5, f"{k}: fused and foreach Adam trajectories differ (max {d.max().item()}, mean {d.mean().item()})"
+        assert d.max().item() <= 8e-3 and d.mean().item() <= 2e-5, f"{k}: fused and foreach Adam trajectories differ (max {d.max().item()}, mean {d.mean().item()})"

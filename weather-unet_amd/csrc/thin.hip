@@ -808,10 +808,6 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_small_kernel(const float
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// conv_last (1x1, Cin -> 3) + tanh.  LP lanes share one pixel (16 B of channels each): a wave load is
-// 64/LP full pixel rows; the three dot products are finished with xor-shuffles.
-// ---------------------------------------------------------------------------------------------------
 // sum over the LP (power of two) consecutive lanes that share a pixel; every lane of the group ends with the total.
 // DPP lane moves folded into the adds (no LDS crossbar): xor 1, xor 2, then mirrors (lane i <-> 7 - i, i <-> 15 - i), which
 // pair equal-valued groups just like xor 4 / xor 8 would.
@@ -828,6 +824,209 @@ __device__ __forceinline__ float lane_group_sum(float v, int LP) {
     if (LP >= 64) v += __shfl_xor(v, 32);
     return v;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// The image-layout 3 -> 3 stride-1 conv of the discriminator (disc.conv1[0], nets.py:28: NCHW fp32 in and out, no activation behind
+// it) through an LDS tile: a workgroup stages a 16 x 64 pixel tile of the three input planes with its one-pixel halo (3 x 18 x 66
+// floats, coalesced rows) and every thread computes FOUR adjacent pixels of one row from it -- 54 LDS reads for 4 x 81 FMAs instead of
+// 27 dependent global loads per pixel (the one-thread-per-pixel kernels above: 74 / 93 / 54 us forward / weight gradient / data
+// gradient at B = 32, 256 x 256, for 50 MB of traffic).
+//   img3_conv_kernel<ACT, false>: y = act(conv(x, w) + bias);   <ACT_NONE, true>: the data gradient = the same conv of dy with the
+//   weights transposed and flipped (w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]), no bias.
+//   img3_wgrad_kernel: dW, dbias partials per workgroup over a grid-stride loop of tiles (fixed order: deterministic).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kI3H = 16, kI3W = 64, kI3P = 68;          // tile rows / columns, LDS row pitch (floats; 16-byte aligned rows)
+
+// acc += a * b as ONE v_fmac_f32, never half of a v_pk_fma_f32.  Measured on MI355X (scratch/img3_concurrency_probe.py, round 3): with
+// the compiler's packed form (162 v_pk_fma_f32 in the conv kernel) a few 16-lane groups per launch came back with ONE accumulator
+// wrong (the low half of a packed pair, off by about one tap's product) whenever the kernel ran on a second stream BESIDE the stem's
+// MFMA kernel (stem7x7_fwd_mfma_kernel: wave64 MFMAs with VGPR accumulators, 220 VGPRs) -- 10 of 10 launches, on several boxes, never
+// alone and never beside VALU-only kernels or the other MFMA kernels; with scalar FMAs 0 of 10.  The library is therefore also built
+// without packed-FP32 VALU ops (wu/_build.py: -target-feature -packed-fp32-ops); this helper keeps the property if that flag is dropped.
+__device__ __forceinline__ void fmac1(float& acc, float a, float b) { asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b)); }
+
+// 54 halo rows (3 planes x 18) of 66 floats: wave w takes rows w, w + 4, ... -- one coalesced 256-byte request per row and wave, all 14
+// issued before the first is stored (the one-loop form waited for every load in turn); the two right-hand halo columns go to 108 threads.
+__device__ __forceinline__ void img3_stage(float (*xs)[kI3H + 2][kI3P], const float* __restrict__ xn, int H, int W, int h0, int w0) {
+    constexpr int R = 3 * (kI3H + 2), NK = (R + 3) / 4;
+    const int lane = threadIdx.x & 63, rsub = threadIdx.x >> 6;
+    const int iw = w0 - 1 + lane;
+    const bool cok = iw >= 0 && iw < W;
+    float v[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int row = rsub + 4 * k, ci = row / (kI3H + 2), r = row - ci * (kI3H + 2), ih = h0 - 1 + r;
+        v[k] = (row < R && cok && ih >= 0 && ih < H) ? xn[((size_t)ci * H + ih) * W + iw] : 0.f;
+    }
+    float ve = 0.f;
+    const int erow = threadIdx.x >> 1, ec = kI3W + (threadIdx.x & 1);
+    if (threadIdx.x < 2 * R) {
+        const int ci = erow / (kI3H + 2), r = erow - ci * (kI3H + 2), ih = h0 - 1 + r, iwe = w0 - 1 + ec;
+        if (ih >= 0 && ih < H && iwe < W) ve = xn[((size_t)ci * H + ih) * W + iwe];
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int row = rsub + 4 * k, ci = row / (kI3H + 2), r = row - ci * (kI3H + 2);
+        if (row < R) xs[ci][r][lane] = v[k];
+    }
+    if (threadIdx.x < 2 * R) xs[erow / (kI3H + 2)][erow % (kI3H + 2)][ec] = ve;
+}
+
+template <int ACT, bool FLIP>
+__global__ __launch_bounds__(256) void img3_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        const float* __restrict__ inv_sigma, float* __restrict__ y, int H, int W,
+                                                        int tiles_x, int tiles_y, int accumulate) {
+    __shared__ __attribute__((aligned(16))) float xs[3][kI3H + 2][kI3P];
+    __shared__ float wl[81], bl[3];
+    const float sc = inv_sigma ? *inv_sigma : 1.f;
+    if (threadIdx.x < 81) {
+        // wl[(ci*9 + tap)*3 + co]
+        const int co = threadIdx.x % 3, k = threadIdx.x / 3, ci = k / 9, t = k % 9;
+        wl[threadIdx.x] = (FLIP ? w[(ci * 3 + co) * 9 + (8 - t)] : w[(co * 3 + ci) * 9 + t]) * sc;
+    }
+    if (threadIdx.x < 3) bl[threadIdx.x] = (!FLIP && bias) ? bias[threadIdx.x] : 0.f;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int h0 = ty * kI3H, w0 = tx * kI3W;
+    const size_t hw = (size_t)H * W;
+    img3_stage(xs, x + (size_t)n * 3 * hw, H, W, h0, w0);
+    __syncthreads();
+    const int r = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+    float acc[3][4];
+#pragma unroll
+    for (int co = 0; co < 3; ++co)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[co][p] = bl[co];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const float4 v4 = *(const float4*)&xs[ci][r + kh][c4];
+            const float v[6] = {v4.x, v4.y, v4.z, v4.w, xs[ci][r + kh][c4 + 4], xs[ci][r + kh][c4 + 5]};
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int co = 0; co < 3; ++co) {
+                    const float ww = wl[((ci * 9) + kh * 3 + kw) * 3 + co];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) fmac1(acc[co][p], v[p + kw], ww);
+                }
+        }
+    const int oh = h0 + r, ow = w0 + c4;
+    if (oh >= H || ow >= W) return;
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+        float* o = y + ((size_t)n * 3 + co) * hw + (size_t)oh * W + ow;
+        float q[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) q[p] = act_apply(acc[co][p], ACT);
+        if (ow + 3 < W && (W & 3) == 0) {
+            float4 ov = make_float4(q[0], q[1], q[2], q[3]);
+            if (accumulate) { const float4 old = *(const float4*)o; ov.x += old.x; ov.y += old.y; ov.z += old.z; ov.w += old.w; }
+            *(float4*)o = ov;
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (ow + p < W) o[p] = accumulate ? o[p] + q[p] : q[p];
+        }
+    }
+}
+
+// part: this workgroup's slice of the partial-sum slab (kC3Slab floats: dW[co*27 + ci*9 + tap] for co < 3, dbias at [81..84)), folded in
+// workgroup order by thin_fold_kernel; NULL: fp32 atomics.  y / act: optional activation gate of dy (unused by the discriminator).
+__global__ __launch_bounds__(256) void img3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ yact,
+                                                         int act, float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ part,
+                                                         int N, int H, int W, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float xs[3][kI3H + 2][kI3P];
+    __shared__ float red[4][84];
+    const size_t hw = (size_t)H * W;
+    const int r = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+    float acc[3][27], bs[3];
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+        bs[co] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[co][k] = 0.f;
+    }
+    const int ntiles = N * tiles_y * tiles_x;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b = tile;
+        const int tx = b % tiles_x; b /= tiles_x;
+        const int ty = b % tiles_y;
+        const int n = b / tiles_y;
+        const int h0 = ty * kI3H, w0 = tx * kI3W;
+        __syncthreads();                                   // the previous tile's readers are done
+        img3_stage(xs, x + (size_t)n * 3 * hw, H, W, h0, w0);
+        const int oh = h0 + r, ow = w0 + c4;
+        float g[3][4];
+        const bool vec = (W & 3) == 0 && oh < H && ow + 3 < W;
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+            const size_t o = ((size_t)n * 3 + co) * hw + (size_t)oh * W + ow;
+            if (vec) {
+                const float4 d4 = *(const float4*)(dy + o);
+                g[co][0] = d4.x; g[co][1] = d4.y; g[co][2] = d4.z; g[co][3] = d4.w;
+                if (yact) {
+                    const float4 y4 = *(const float4*)(yact + o);
+                    g[co][0] = act_gate(g[co][0], y4.x, act); g[co][1] = act_gate(g[co][1], y4.y, act);
+                    g[co][2] = act_gate(g[co][2], y4.z, act); g[co][3] = act_gate(g[co][3], y4.w, act);
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float v = 0.f;
+                    if (oh < H && ow + p < W) {
+                        v = dy[o + p];
+                        if (yact) v = act_gate(v, yact[o + p], act);
+                    }
+                    g[co][p] = v;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) bs[co] += g[co][p];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float4 v4 = *(const float4*)&xs[ci][r + kh][c4];
+                const float v[6] = {v4.x, v4.y, v4.z, v4.w, xs[ci][r + kh][c4 + 4], xs[ci][r + kh][c4 + 5]};
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int co = 0; co < 3; ++co)
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) fmac1(acc[co][ci * 9 + kh * 3 + kw], g[co][p], v[p + kw]);
+            }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            float v = acc[co][k];
+            v = lane_group_sum(v, 64);
+            if (lane == 0) red[wave][co * 27 + k] = v;
+        }
+        float bsum = lane_group_sum(bs[co], 64);
+        if (lane == 0) red[wave][81 + co] = bsum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 84) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float* mine = part ? part + (size_t)blockIdx.x * kC3Slab : nullptr;
+        if (threadIdx.x < 81) { if (mine) mine[threadIdx.x] = v; else atomicAdd(&dw[threadIdx.x], v); }
+        else if (dbias) { if (mine) mine[threadIdx.x] = v; else atomicAdd(&dbias[threadIdx.x - 81], v); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv_last (1x1, Cin -> 3) + tanh.  LP lanes share one pixel (16 B of channels each): a wave load is
+// 64/LP full pixel rows; the three dot products are finished with xor-shuffles.
+// ---------------------------------------------------------------------------------------------------
 // tanh(s) = 1 - 2 / (exp(2 s) + 1) on the hardware exp2 / rcp units: absolute error ~2e-7 (the library tanhf is ~40 VALU
 // instructions, which made the forward head VALU-bound); saturates correctly (exp -> inf gives 1, exp -> 0 gives -1)
 __device__ __forceinline__ float fast_tanh(float s) {
@@ -979,7 +1178,12 @@ static int c3_fwd_impl(const float* x_nchw, const float* w_oihw, const float* bi
 #define C3_MFMA(ST) do { if (act == WU_ACT_RELU) C3_MFMA_A(ST, WU_ACT_RELU); else if (act == WU_ACT_LEAKY) C3_MFMA_A(ST, WU_ACT_LEAKY); else C3_MFMA_A(ST, WU_ACT_NONE); } while (0)
     const int grid_m = grid_cap((long long)N * Ho * Wo, 128, 256 * 16);
     // option 5: 0 = bf16 on the matrix cores (default), 1 = scalar-weight rows kernel, 2 = one-thread-per-pixel VALU kernel
-    if (out_nchw) C3_LAUNCH(float, 3, 1, true);
+    if (out_nchw && g_wu_opt[WU_OPT_IMG3_TILED] && (long long)N * cdiv(H, kI3H) * cdiv(W, kI3W) < (1ll << 31)) {          // the LDS-tiled image-layout 3 -> 3 conv
+        const int tx_ = cdiv(W, kI3W), ty_ = cdiv(H, kI3H);
+#define I3F(A) hipLaunchKernelGGL((img3_conv_kernel<A, false>), dim3((unsigned)(N * tx_ * ty_)), dim3(256), 0, s, x_nchw, w_oihw, bias, inv_sigma, (float*)y, H, W, tx_, ty_, 0)
+        if (act == WU_ACT_RELU) I3F(WU_ACT_RELU); else if (act == WU_ACT_LEAKY) I3F(WU_ACT_LEAKY); else I3F(WU_ACT_NONE);
+#undef I3F
+    } else if (out_nchw) C3_LAUNCH(float, 3, 1, true);
     else if (c3_fwd_mfma_ok(N, H, W, Cout, stride, bias, dtype)) { if (stride == 1) C3_MFMA(1); else C3_MFMA(2); }
     else if (g_wu_opt[WU_OPT_C3_ROWS] == 1) {
         if (dtype == WU_BF16) { if (stride == 1) C3_LANES(bf16_t, 1); else C3_LANES(bf16_t, 2); }
@@ -1044,6 +1248,14 @@ extern "C" int wu_conv3x3_c3_wgrad(const float* x_nchw, const void* dy, int lddy
         WU_LAUNCH_CHECK("conv3x3_c3_wgrad_mfma");
         return 0;
     }
+    if (dy_nchw && Cout == 3 && stride == 1 && g_wu_opt[WU_OPT_IMG3_TILED] && (long long)N * cdiv(H, kI3H) * cdiv(W, kI3W) < (1ll << 31)) {
+        const int tx_ = cdiv(W, kI3W), ty_ = cdiv(H, kI3H);
+        const int g = grid_cap((long long)N * tx_ * ty_, 1, kThinMaxBlocks);
+        hipLaunchKernelGGL(img3_wgrad_kernel, dim3(g), dim3(256), 0, s, x_nchw, (const float*)dy, (const float*)y, act, dw_oihw, dbias, part, N, H, W, tx_, ty_);
+        if (part) hipLaunchKernelGGL(thin_fold_kernel, dim3(cdiv(84, 8)), dim3(256), 0, s, part, g, kC3Slab, dw_oihw, 81, dbias, dbias ? 3 : 0, accumulate);
+        WU_LAUNCH_CHECK("img3_wgrad");
+        return 0;
+    }
     if (dy_nchw && Cout <= 3) {
         const int g = grid_cap((long long)N * Ho * Wo, 256, 1024);
         if (stride == 1) hipLaunchKernelGGL(conv3x3_c3_wgrad_small_kernel<1>, dim3(g), dim3(256), 0, s, x_nchw, (const float*)dy, (const float*)y, act, dw_oihw, dbias, part, N, H, W, Cout);
@@ -1092,6 +1304,13 @@ extern "C" int wu_conv3x3_c3_dgrad(const void* dy, int lddy, int dy_nchw, const 
         else { if (stride == 1) C3DN(float, 1); else C3DN(float, 2); }
 #undef C3DN
         WU_LAUNCH_CHECK("conv3x3_c3_dgrad_nhwc");
+        return 0;
+    }
+    if (dy_nchw && Cout == 3 && stride == 1 && !y && g_wu_opt[WU_OPT_IMG3_TILED] && (long long)N * cdiv(H, kI3H) * cdiv(W, kI3W) < (1ll << 31)) {
+        const int tx_ = cdiv(W, kI3W), ty_ = cdiv(H, kI3H);       // = the forward conv of dy with transposed, flipped weights
+        hipLaunchKernelGGL((img3_conv_kernel<WU_ACT_NONE, true>), dim3((unsigned)(N * tx_ * ty_)), dim3(256), 0, s, (const float*)dy, w_oihw, (const float*)nullptr,
+                           inv_sigma, dx_nchw, H, W, tx_, ty_, accumulate);
+        WU_LAUNCH_CHECK("img3_dgrad");
         return 0;
     }
 #define C3D(T, ST, NCHW) hipLaunchKernelGGL((conv3x3_c3_dgrad_kernel<T, ST, NCHW>), dim3(grid), dim3(256), lds, s, dy, lddy, y, ldy_, act, w_oihw, inv_sigma, dx_nchw, N, H, W, Cout, accumulate)

@@ -15,7 +15,12 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libwu_kernels.so")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I", INCLUDE]
+# -packed-fp32-ops: no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 in the device code.  Round 3 measured packed-FP32 results of one
+# kernel corrupted (single 16-lane groups, a few per launch) while it shared SIMDs with the MFMA waves of ANOTHER kernel running on a
+# second stream (csrc/thin.hip: fmac1); the kernels are HBM- or MFMA-bound, the packed forms bought nothing measurable
+# (profiles/r03_packed_fp32_ab.txt).  WU_PACKED_FP32=1 builds with them again (A/B work only).
+NO_PACKED_FP32 = [] if os.environ.get("WU_PACKED_FP32") == "1" else ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-inline-asm"] + NO_PACKED_FP32 + ["-I", INCLUDE]
 
 
 def sources():
@@ -32,7 +37,7 @@ def _headers():
 def source_hash(src=None):
     """sha256 over the compile flags, every header and `src` (or all sources): what an object / the library was built FROM.
     Content, not mtimes: a checkout, a copy to another box or a touched file cannot make a stale object look fresh."""
-    h = hashlib.sha256(" ".join(FLAGS[:5]).encode())
+    h = hashlib.sha256(" ".join(FLAGS[:-2]).encode())
     for f in _headers() + ([src] if src else sources()):
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
@@ -73,7 +78,13 @@ def build(force=False, verbose=True):
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        # the HOST pass of a .hip file does not know the AMDGPU feature name and says so once per function set: not a diagnostic
+        err = "\n".join(ln for ln in r.stderr.splitlines() if "packed-fp32-ops' is not a recognized feature" not in ln)
+        if err.strip():
+            print(err, file=sys.stderr, flush=True)
+        if r.returncode:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))

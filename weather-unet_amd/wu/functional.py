@@ -180,9 +180,11 @@ class ConvC3Fn(Function):
         cout = wt.shape[0]
         gy = gy.float().contiguous() if out_nchw else _grad_nhwc(gy, code)
         gate = y if act != ACT_NONE else None
-        dw = torch.empty(wt.shape, dtype=torch.float32, device=x.device)
-        db = torch.empty((cout,), dtype=torch.float32, device=x.device) if has_bias else None
-        K.conv3x3_c3_wgrad(x, gy, dw, db, stride, code, dy_nchw=out_nchw, y=gate, act=act)
+        dw = db = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):      # frozen in the generator update (wu/train_step.py)
+            dw = torch.empty(wt.shape, dtype=torch.float32, device=x.device)
+            db = torch.empty((cout,), dtype=torch.float32, device=x.device) if has_bias else None
+            K.conv3x3_c3_wgrad(x, gy, dw, db, stride, code, dy_nchw=out_nchw, y=gate, act=act)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
