@@ -8,6 +8,7 @@ normalisations of a forward (one power iteration each in training mode, as torch
 The feature maps c1..c4 are returned as NHWC-strided tensors of the compute dtype (logical NCHW shape).
 """
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -22,6 +23,9 @@ from wu.layout import precision_code, require_cuda
 
 # one batched spectral normalisation per forward (default) or one per layer (A/B switch, WU_SN_BATCHED=0)
 BATCHED_SPECTRAL_NORM = os.environ.get("WU_SN_BATCHED", "1") == "1"
+
+
+_SN_DONE = weakref.WeakKeyDictionary()
 
 
 class SNDisc(nn.Module):
@@ -56,6 +60,12 @@ class SNDisc(nn.Module):
             m.set_precision(precision)
         return self
 
+    @property
+    def sn_done(self):
+        """Event recorded (on the stream of the forward) once the last forward's batched normalisation was enqueued; None before
+        the first one.  Kept outside the module's attributes: events cannot be deep-copied or pickled."""
+        return _SN_DONE.get(self)
+
     def sn_layers(self):
         """The ten spectrally normalised layers in forward order."""
         return [m for i in range(1, 5) for m in getattr(self, 'conv{}'.format(i))[:2]] + [self.l, self.embed]
@@ -70,6 +80,10 @@ class SNDisc(nn.Module):
         train = layers[0].training
         w_eff = WF.spectral_normalize_multi([m.weight_orig for m in layers], [m.weight_u for m in layers], [m.weight_v for m in layers],
                                             train, layers[0].eps)
+        ev = _SN_DONE.get(self)
+        if ev is None:
+            ev = _SN_DONE[self] = torch.cuda.Event()
+        ev.record()                                          # the power-iteration buffers are final for this forward (wu/train_step.py)
         for m, w in zip(layers, w_eff):
             if train:
                 m._sn_generation += 1

@@ -25,6 +25,7 @@ Differences from the reference loop, all numerically neutral:
     not all-reduced.
 """
 import os
+import warnings
 
 import torch
 import torch.nn as nn
@@ -37,6 +38,11 @@ from wu.ddp import GradBucketReducer, broadcast_buffers, is_distributed, ready_o
 
 # update_inference: the discriminator's pass over the fake batch on a second stream, beside the estimator's (A/B switch)
 OVERLAP_D_WITH_ESTIMATOR = os.environ.get("WU_GAN_OVERLAP", "1") == "1"
+# update_discriminator: the discriminator's real-batch and fake-batch passes on two streams (A/B switch)
+OVERLAP_D_PASSES = os.environ.get("WU_GAN_OVERLAP_D", "1") == "1"
+# with a pass on the second stream, a parameter's AccumulateGrad node (created on the main stream) receives gradients produced on the
+# other one: autograd synchronises the two correctly and says so once per backward (a note about CUDA-graph capture, not an error)
+warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
 
 
 class StandInEstimator(nn.Module):
@@ -114,7 +120,22 @@ class WeatherTransferStep:
                 pred_labels = self.estimator(images)                                     # :297
             fake_out = self.inference(images, labels)                                    # :302-303
         real_d_out_pred = self.discriminator(images, pred_labels)[0]                     # :299
-        fake_d_out = self.discriminator(fake_out, labels)[0]
+        sn_done = getattr(self.discriminator, "sn_done", None)
+        if OVERLAP_D_PASSES and self.d_red is None and images.is_cuda and sn_done is not None:
+            # The pass over the fake batch runs on the second stream beside the pass over the real batch (and so do the two
+            # backward chains): the kernels of one pass at B = 32 leave much of the chip idle.  The only coupling between the passes
+            # is the power-iteration state -- pass 2 iterates the u / v that pass 1's iteration left (disc.py: one iteration per
+            # forward) -- so the second stream starts after the FIRST pass's batched normalisation (SNDisc.sn_done), not after its
+            # convs.  Without a gradient reducer only: its hooks assume one producing stream.
+            main, side = torch.cuda.current_stream(images.device), self._d_stream(images.device)
+            side.wait_event(sn_done)                       # recorded on `main` after G's forward and pass 1's normalisation
+            fake_out.record_stream(side)
+            with torch.cuda.stream(side):
+                fake_d_out = self.discriminator(fake_out, labels)[0]
+            fake_d_out.record_stream(main)
+            main.wait_stream(side)
+        else:
+            fake_d_out = self.discriminator(fake_out, labels)[0]
         d_loss = ops.dis_hinge(fake_d_out, real_d_out_pred)                              # :305
         d_loss.backward()
         if self.d_red is not None:
