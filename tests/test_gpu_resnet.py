@@ -74,7 +74,7 @@ def test_conv1x1_gemm(p, shape):
 
 
 @pytest.mark.parametrize("p", ["fp32", "bf16"])
-@pytest.mark.parametrize("hw", [(64, 64), (45, 70)])
+@pytest.mark.parametrize("hw", [(64, 64), (45, 70), (40, 72), (96, 160)])
 def test_stem_and_maxpool(p, hw):
     from wu import resnet as RN
     from wu.layout import empty_nhwc, precision_code
@@ -105,7 +105,12 @@ def test_stem_and_maxpool(p, hw):
     g1 = _rnd(_rand((n, 64, h1, w1), 15), p)
     F.conv2d(xr, wt, None, stride=2, padding=3).backward(g1)
     dx = RN.stem7x7_dgrad(_nhwc(g1, p), wt.to(DEV), torch.empty((n, 3, h, w), device=DEV), code)
-    assert (dx.cpu() - xr.grad).abs().max().item() <= 2e-4 * max(1.0, xr.grad.abs().max().item())
+    # bf16 with even H, W: the matrix-core kernel, weights rounded to bf16 like every other bf16 layer (the VALU kernel of the odd
+    # sizes and of fp32 multiplies by the fp32 weights)
+    dtol = 2e-4 if (p == "fp32" or h % 2 or w % 2) else 5e-3
+    assert (dx.cpu() - xr.grad).abs().max().item() <= dtol * max(1.0, xr.grad.abs().max().item())
+    dx2 = RN.stem7x7_dgrad(_nhwc(g1, p), wt.to(DEV), dx.clone(), code, accumulate=True)
+    assert (dx2 - 2 * dx).abs().max().item() <= 1e-5 * max(1.0, dx.abs().max().item())
 
 
 def _est(nc, seed, precision, layers):

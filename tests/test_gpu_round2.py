@@ -493,6 +493,10 @@ def test_three_step_trajectory_fused_vs_foreach_adam():
     # (2 lr apart).  Step 1 sees identical gradients; the two implementations' last-bit differences then perturb the gradients of steps
     # 2 and 3, so the worst case is two opposite steps = 4 lr = 8e-3 (observed 1.2e-3 ... 5.0e-3 on single elements, depending on the
     # build); the bulk must agree to rounding (mean)
+    # What the test guards against -- a forward that convolves with the weights of an EARLIER step -- moves every element by about lr per
+    # step (mean difference ~1e-3, most elements above 1e-3): the bounds sit an order of magnitude below that signature and above the
+    # sign-flip noise (a 512-element bias with two flipped elements has a mean difference of 2e-5)
     for k in pa:
         d = (pa[k].float() - pb[k].float()).abs()
-        assert d.max().item() <= 8e-3 and d.mean().item() <= 2e-5, f"{k}: fused and foreach Adam trajectories differ (max {d.max().item()}, mean {d.mean().item()})"
+        assert d.max().item() <= 8e-3 and d.mean().item() <= 1e-4 and (d > 1e-3).float().mean().item() <= 0.02, \
+            f"{k}: fused and foreach Adam trajectories differ (max {d.max().item()}, mean {d.mean().item()}, share above 1e-3 {(d > 1e-3).float().mean().item()})"

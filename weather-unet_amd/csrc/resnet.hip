@@ -520,6 +520,138 @@ __global__ __launch_bounds__(256) void stem7x7_dgrad_kernel(const T* __restrict_
     }
 }
 
+// bf16 stem data gradient on the matrix cores (round 3; the formulation of conv3x3_c3_dgrad_s2_mfma_kernel, thin.hip).  The VALU kernel
+// above spends ~150 LDS-fed FMAs per input pixel and channel octet and is instruction-bound (432 us at B = 32 for 92 MB of traffic).
+// Here, per OUTPUT pixel q and image channel c, the 49 products  P_c[k][q] = sum_co W[co][c][k] * dY[q][co]  (k = kh*7 + kw, padded to
+// 64 rows) are two 32 x 32 x 64 MFMA blocks per 32 pixels; an INPUT pixel then sums the 9 / 12 / 16 entries of P_c whose taps have its
+// parity, in (kh, kw) order -- no atomics, deterministic.  A workgroup takes 16 x 32 input pixels = the 11 x 19 output pixels that reach
+// them (dY fragments loaded once into registers, 7 blocks of 32 over 4 waves), channel by channel through one 49 x 225 fp32 LDS
+// image; the 24 weight fragments (3 channels x 2 row blocks x 4 k-steps) are built once per workgroup, which is persistent over tiles.
+constexpr int kDGH = 16, kDGW = 32, kDQH = kDGH / 2 + 3, kDQW = kDGW / 2 + 3, kDQN = kDQH * kDQW;       // 11 x 19 = 209 output pixels
+constexpr int kDQB = (kDQN + 31) / 32, kDPS = kDQB * 32 + 1;                                            // 7 blocks; P row pitch 225
+
+// sum of the taps of parity (PH, PW) for the input pixel whose P base is pb = P + (row / 2) * 19 + col / 2, in (kh, kw) order
+template <int PH, int PW>
+__device__ __forceinline__ float dg_gather(const float* __restrict__ pb) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int kh = (PH + 3) & 1; kh < 7; kh += 2)
+#pragma unroll
+        for (int kw = (PW + 3) & 1; kw < 7; kw += 2)
+            sacc += pb[(kh * 7 + kw) * kDPS + ((PH + 3 - kh) / 2 + 1) * kDQW + ((PW + 3 - kw) / 2 + 1)];
+    return sacc;
+}
+
+__global__ __launch_bounds__(256, 2) void stem7x7_dgrad_mfma_kernel(const bf16_t* __restrict__ dy, int lddy, const float* __restrict__ w,
+                                                                    float* __restrict__ dx, int N, int H, int W, int Ho, int Wo,
+                                                                    int tiles_x, int tiles_y, int accumulate) {
+    __shared__ float P[49 * kDPS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    // weights as the MFMA A operand: row k = 32 kb + l31 (49 real rows), reduction index co = 16 ks + 8 lh + j.  The OIHW tensor goes
+    // through LDS once (coalesced; 192 strided global loads per lane took longer than a tile), the fragments then live in registers
+    static_assert(64 * 147 <= 49 * kDPS, "the weight image must fit the P buffer");
+    for (int i = tid; i < 64 * 147; i += 256) P[i] = w[i];
+    __syncthreads();
+    uint4 wf[3][2][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = 32 * kb + l31;
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = k < 49 ? P[((16 * ks + 8 * lh + j) * 3 + c) * 49 + k] : 0.f;
+                wf[c][kb][ks] = pack16<bf16_t>(f);
+            }
+    const int ntiles = N * tiles_x * tiles_y;
+    const size_t hw = (size_t)H * W;
+    // dY fragments of this wave's blocks (wave, wave + 4) of one tile: pixel q = 32 b + l31 -> (q / 19, q % 19); the NEXT tile's are
+    // requested before the current tile is worked on
+    auto load_dy = [&](int tile, uint4 (&av)[2][4], unsigned (&mk)[2]) __attribute__((always_inline)) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y, n = t / tiles_y;
+        const int oh0 = ty * kDGH / 2 - 1, ow0 = tx * kDGW / 2 - 1;      // first output row / column that reaches the tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int b = wave + 4 * i;
+            const int q = 32 * b + l31, r = q / kDQW, cc = q - r * kDQW;
+            const int oh = oh0 + r, ow = ow0 + cc;
+            const bool ok = tile < ntiles && b < kDQB && q < kDQN && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
+            const size_t op = ((size_t)min(n, N - 1) * Ho + min(max(oh, 0), Ho - 1)) * Wo + min(max(ow, 0), Wo - 1);
+            mk[i] = ok ? 0xffffffffu : 0u;                  // lane mask instead of a 128-bit select, applied where the fragment is used
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) av[i][ks] = *(const uint4*)(dy + op * lddy + 16 * ks + 8 * lh);
+        }
+    };
+    uint4 av[2][4], avn[2][4];
+    unsigned mka[2], mkn[2];
+    load_dy(blockIdx.x, av, mka);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y, n = t / tiles_y;
+        const int ih0 = ty * kDGH, iw0 = tx * kDGW;
+        load_dy(tile + gridDim.x, avn, mkn);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)                          // the current tile's fragments: out-of-image pixels contribute zero
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) av[i][ks] = make_uint4(av[i][ks].x & mka[i], av[i][ks].y & mka[i], av[i][ks].z & mka[i], av[i][ks].w & mka[i]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                         // unrolled: wf[c] must be a register, not an indexed (scratch) array
+            __syncthreads();                                  // the previous channel's (tile's) gather is done with P
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int b = wave + 4 * i;
+                if (b >= kDQB) break;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    f32x16_t acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[c][kb][ks]), __builtin_bit_cast(bf16x8_t, av[i][ks]), acc, 0, 0, 0);
+                    }
+                    // lane (pixel l31, half lh) holds rows k = 32 kb + 8 g + 4 lh + e of its pixel's column
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = 32 * kb + 8 * g + 4 * lh + e;
+                            if (k < 49) P[k * kDPS + 32 * b + l31] = acc[4 * g + e];
+                        }
+                }
+            }
+            __syncthreads();
+            // ---- input pixels (ih0 + row, iw0 + col): taps of matching parity, summed in (kh, kw) order.  A thread takes the two
+            // pixels (row, 2 cb) and (row, 2 cb + 1) -- one 8-byte store -- of a row whose parity is fixed per 16-lane group, so every
+            // P address is base + a compile-time offset (the generic loops cost ~500 instructions per pixel: the kernel was VALU-bound)
+            {
+                const int cb = tid & 15, ph = (tid >> 4) & 1, rb = tid >> 5;
+                const int row = 2 * rb + ph, ih = ih0 + row, iw = iw0 + 2 * cb;
+                const float* pb = P + rb * kDQW + cb;
+                float s0, s1;
+                if (ph) { s0 = dg_gather<1, 0>(pb); s1 = dg_gather<1, 1>(pb); }
+                else { s0 = dg_gather<0, 0>(pb); s1 = dg_gather<0, 1>(pb); }
+                if (ih < H && iw < W) {                          // W is even: the pair is inside or outside together
+                    float2* o = (float2*)(dx + ((size_t)n * 3 + c) * hw + (size_t)ih * W + iw);
+                    float2 v = make_float2(s0, s1);
+                    if (accumulate) { const float2 old = *o; v.x += old.x; v.y += old.y; }
+                    *o = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) av[i][ks] = avn[i][ks];
+        mka[0] = mkn[0]; mka[1] = mkn[1];
+    }
+}
+
 // =================================================================================================
 // MaxPool2d(kernel 3, stride 2, pad 1), NHWC, with the window-local arg-max (0..8, first maximum in scan order) kept for backward
 // =================================================================================================
@@ -699,6 +831,17 @@ extern "C" int wu_stem7x7_dgrad(const void* dy, int lddy, const float* w_oihw, f
     WU_REQUIRE((long long)N * H * W < (1ll << 31), "stem7x7_dgrad: N*H*W must stay below 2^31");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long pixels = (long long)N * H * W;
+    if (dtype == WU_BF16 && lddy % 8 == 0 && H % 2 == 0 && W % 2 == 0) {       // even sizes: a tile's output window starts at ih0 / 2 - 1
+        const int tx_ = cdiv_dev(W, kDGW), ty_ = cdiv_dev(H, kDGH);
+        const long long nt = (long long)N * tx_ * ty_;
+        if (nt < (1ll << 31)) {
+            const int g = (int)(nt < 2ll * wu_num_cus() ? nt : 2ll * wu_num_cus());
+            hipLaunchKernelGGL(stem7x7_dgrad_mfma_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, w_oihw, dx_nchw,
+                               N, H, W, Ho, Wo, tx_, ty_, accumulate);
+            WU_LAUNCH_CHECK("stem7x7_dgrad_mfma");
+            return 0;
+        }
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(stem7x7_dgrad_kernel<T>, dim3(grid_cap(pixels, 32, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
                                          (const T*)dy, lddy, w_oihw, dx_nchw, N, H, W, Ho, Wo, accumulate));
     WU_LAUNCH_CHECK("stem7x7_dgrad");
