@@ -22,8 +22,11 @@ def main():
         ts = []
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1) * 1e3)
+            e0.record()
+            for _ in range(8):                 # back-to-back: a single launch's event pair reads a ~10 us floor
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / 8)
         return statistics.median(ts)
 
     tot = 0.0

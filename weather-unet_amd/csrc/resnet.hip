@@ -112,24 +112,29 @@ __global__ __launch_bounds__(256, TM == 256 ? 2 : (TM == 128 ? 3 : 4)) void conv
 #pragma unroll
     for (int k = 0; k < 2; ++k) wsrc[k] = (const T*)a.w + (size_t)(co0 + srow + 32 * k) * a.Cin + sslot * E16;
 
-    uint4 areg[NA], wr0, wr1;            // the weight pair is named, not an array: hipcc parks a small array of uint4 in scratch here
-    auto load_step = [&](int c0) __attribute__((always_inline)) {
+    // TWO register sets: the global loads of step c + 2 are issued before step c is computed and are still in flight when step c + 1's
+    // are written to LDS (counted waits: the sets are indexed at compile time by an unrolled-by-two loop).  These GEMMs are 1-16 K steps
+    // long with one or two workgroups per CU: one step ahead exposed a full memory round trip (~1 us) per K step.
+    uint4 areg[2][NA], w00, w01, w10, w11;      // the weight registers are named, not an array: hipcc parks a small array of uint4 in scratch here
+    auto load_step = [&](auto SET, int c0) __attribute__((always_inline)) {
+        constexpr int S = decltype(SET)::value;
 #pragma unroll
-        for (int k = 0; k < NA; ++k) areg[k] = *(const uint4*)(asrc[k] + c0);
-        wr0 = *(const uint4*)(wsrc[0] + c0);
-        wr1 = *(const uint4*)(wsrc[1] + c0);
+        for (int k = 0; k < NA; ++k) areg[S][k] = *(const uint4*)(asrc[k] + c0);
+        if constexpr (S == 0) { w00 = *(const uint4*)(wsrc[0] + c0); w01 = *(const uint4*)(wsrc[1] + c0); }
+        else { w10 = *(const uint4*)(wsrc[0] + c0); w11 = *(const uint4*)(wsrc[1] + c0); }
     };
-    auto store_step = [&](int stage) __attribute__((always_inline)) {
+    auto store_step = [&](auto SET, int stage) __attribute__((always_inline)) {
+        constexpr int S = decltype(SET)::value;
         char* a_lds = smem + stage * kStage;
         char* w_lds = a_lds + TM * kKB;
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             // rows past the end of the GEMM are zeroed with a lane mask (a 128-bit select is lowered through scratch memory)
             const uint32_t m = aok[k] ? 0xffffffffu : 0u;
-            *(uint4*)(a_lds + pw_off(srow + 32 * k, sslot)) = make_uint4(areg[k].x & m, areg[k].y & m, areg[k].z & m, areg[k].w & m);
+            *(uint4*)(a_lds + pw_off(srow + 32 * k, sslot)) = make_uint4(areg[S][k].x & m, areg[S][k].y & m, areg[S][k].z & m, areg[S][k].w & m);
         }
-        *(uint4*)(w_lds + pw_off(srow, sslot)) = wr0;
-        *(uint4*)(w_lds + pw_off(srow + 32, sslot)) = wr1;
+        *(uint4*)(w_lds + pw_off(srow, sslot)) = S == 0 ? w00 : w10;
+        *(uint4*)(w_lds + pw_off(srow + 32, sslot)) = S == 0 ? w01 : w11;
     };
 
     // accumulators TRANSPOSED (weights are the MFMA A operand): a lane owns 4 consecutive channels of one pixel per register quad
@@ -141,14 +146,17 @@ __global__ __launch_bounds__(256, TM == 256 ? 2 : (TM == 128 ? 3 : 4)) void conv
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
-    // K loop, two LDS stages: the global loads of step c+1 are in flight under the MFMAs of step c and land in the OTHER stage,
-    // so one barrier per step suffices (everyone has left stage (c+1)&1 when it passed the barrier that published stage c&1)
+    // K loop, two LDS stages + two register sets: step c is computed from stage c & 1 while step c + 1 sits in registers (written to
+    // the OTHER stage after the compute: everyone left it when it passed the barrier that published stage c & 1) and step c + 2 is on
+    // its way from memory
     const int nsteps = a.Cin / KE;
-    load_step(0);
-    store_step(0);
-    __syncthreads();
-    for (int c = 0; c < nsteps; ++c) {
-        if (c + 1 < nsteps) load_step((c + 1) * KE);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    auto step = [&](auto CUR, auto NXT, auto LOAD, int c) __attribute__((always_inline)) {
+        // CUR: the register set step c came through (free again), NXT: the set holding step c + 1.  LOAD (compile time): step c + 2
+        // exists and is requested now -- unconditionally, so that the number of loads in flight at the LDS store below is a constant
+        // the compiler can count (behind a run-time `if` it waited for ALL loads there: one step in flight again)
+        if constexpr (decltype(LOAD)::value) load_step(CUR, (c + 2) * KE);
         const char* a_lds = smem + (c & 1) * kStage;
         const char* w_lds = a_lds + TM * kKB;
 #pragma unroll
@@ -163,10 +171,29 @@ __global__ __launch_bounds__(256, TM == 256 ? 2 : (TM == 128 ? 3 : 4)) void conv
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) PwMma<T>::run(acc[mi][ni], bf[ni], af[mi]);      // D^T = W * X^T
         }
-        if (c + 1 < nsteps) {
-            store_step((c + 1) & 1);
+        if (decltype(LOAD)::value || c + 1 < nsteps) {
+            store_step(NXT, (c + 1) & 1);
             __syncthreads();
         }
+    };
+    using YES = std::true_type;
+    using NO = std::false_type;
+    load_step(S0{}, 0);
+    if (nsteps > 1) load_step(S1{}, KE);
+    store_step(S0{}, 0);
+    __syncthreads();
+    int c = 0;
+    for (; c + 3 < nsteps; c += 2) {            // both steps of a pair have a step two ahead of them
+        step(S0{}, S1{}, YES{}, c);
+        step(S1{}, S0{}, YES{}, c + 1);
+    }
+    if (c + 2 < nsteps) {                       // three steps left
+        step(S0{}, S1{}, YES{}, c);
+        step(S1{}, S0{}, NO{}, c + 1);
+        step(S0{}, S1{}, NO{}, c + 2);
+    } else {                                    // one or two
+        step(S0{}, S1{}, NO{}, c);
+        if (c + 1 < nsteps) step(S1{}, S0{}, NO{}, c + 1);
     }
 
     // ---- direct register epilogue: bias + residual in fp32, activation, gate, 8-byte (bf16) / 16-byte (fp32) stores ----
