@@ -212,12 +212,13 @@ def main():
     do_roof = (not a.no_roofline) and rank == 0
     pre_stats = None
     families_timed = families
-    if not a.no_roofline and not a.fwd_only:
-        # The hipEvent pair around an instrumented launch costs ~5 us of stream time: 39 pairs are 0.19 ms of the 8.5 ms U-Net step
-        # (same-box A/B against --no-roofline, profiles/r03_roofline_overhead.txt), ~550 pairs 3.5 ms of a 31 ms GAN iteration.  One
-        # extra, untimed, fully instrumented iteration finds the dominant family and gives the other families' figures; the timed
-        # region then brackets the dominant family only (every one of its launches).  Every rank runs the extra iteration (it
-        # contains the gradient all-reduce); rank 0 alone instruments it.
+    if not a.no_roofline and gan is not None:
+        # GAN workloads launch ~550 instrumented kernels per iteration and the hipEvent pair around each costs ~5 us of stream time
+        # (3.5 ms of a 31 ms iteration).  One extra, untimed, fully instrumented iteration finds the dominant family and gives the
+        # other families' figures; the timed region then brackets the dominant family only (every one of its launches).  Every rank
+        # runs the extra iteration (it contains the gradient all-reduce); rank 0 alone instruments it.  The U-Net step keeps all three
+        # families bracketed: its 13 weight-gradient pairs sit on the side stream, off the critical path -- leaving them out changed
+        # neither the step time nor the overhead (0.18 ms against --no-roofline either way, profiles/r03_roofline_overhead.txt).
         if do_roof:
             _lib.prof_begin(families, 1024 + 64)
         step()
