@@ -623,3 +623,45 @@ def test_sndisc_batched_normalisation_matches_per_layer_path():
             assert ka == kb and torch.equal(ta, tb), ka
         for (ka, pa), (_, pb) in zip(Da.named_parameters(), Db.named_parameters()):
             assert pa.grad is not None and torch.equal(pa.grad, pb.grad), ka
+
+
+def test_tiled_image_conv_beside_the_stem_mfma_kernel():
+    """Regression test for the cross-stream hazard of DESIGN.md 4: the LDS-tiled image-layout 3 -> 3 conv (forward and its
+    transposed-weight data-gradient form) must give bit-identical results when it runs on a second stream BESIDE the stem's MFMA
+    kernel (the arrangement of WeatherTransferStep.update_inference: D's first conv beside the estimator's stem).  With packed-FP32
+    FMAs in the kernel 10 of 10 launches came back with a few wrong 16-lane groups; a blocker on the main stream makes the two
+    kernels start together."""
+    from wu import _lib, kernels as K, resnet as RN
+    from wu.layout import empty_nhwc
+    from wu.unet_graph import _side_stream
+    dev = torch.device("cuda:0")
+    B, S, code = 32, 256, _lib.BF16
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = (torch.rand((B, 3, S, S), generator=g) * 2 - 1).to(dev)
+    w33 = ((torch.rand((3, 3, 3, 3), generator=g) - 0.5) * 0.3).to(dev)
+    b3 = (torch.rand(3, generator=g) - 0.5).to(dev)
+    ws = ((torch.rand((64, 3, 7, 7), generator=g) - 0.5) * 0.1).to(dev)
+    bs = (torch.rand(64, generator=g) - 0.5).to(dev)
+    stem_y = empty_nhwc(B, 64, S // 2, S // 2, torch.bfloat16, dev)
+    main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    subjects = {"forward": lambda out: K.conv3x3_c3(x, w33, b3, out, 1, 0, True, code),
+                "data gradient": lambda out: K.conv3x3_c3_dgrad(x, w33, out, 1, code, dy_nchw=True)}
+    RN.stem7x7(x, ws, bs, stem_y, 1, code)
+    torch.cuda.synchronize()
+    stem_ref = stem_y.clone()
+    for name, subj in subjects.items():
+        ref = torch.empty_like(x)
+        subj(ref)
+        torch.cuda.synchronize()
+        for _ in range(6):
+            out = torch.full_like(x, float("nan"))
+            torch.cuda.synchronize()
+            torch.cuda._sleep(3_000_000)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                subj(out)
+            RN.stem7x7(x, ws, bs, stem_y, 1, code)
+            main.wait_stream(side)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), f"{name}: differs beside the stem kernel (max {(out - ref).abs().nan_to_num(1e9).max().item():.3e})"
+            assert torch.equal(stem_y, stem_ref)
