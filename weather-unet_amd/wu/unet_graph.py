@@ -48,7 +48,8 @@ def _side_stream(dev):
         import os
         import statistics
         import time
-        cands = [torch.cuda.Stream(device=dev) for _ in range(5)]
+        prio = int(os.environ.get("WU_SIDE_STREAM_PRIORITY", "0"))       # A/B switch: -1 = high priority (torch has two levels)
+        cands = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(5)]
         spin = 1_000_000
         torch.cuda._sleep(spin)                      # warm the spin kernel
         times = [[] for _ in cands]
