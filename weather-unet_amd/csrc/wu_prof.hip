@@ -80,7 +80,11 @@ extern "C" int wu_prof_begin(unsigned family_mask, int max_launches) {
     g_prof.ev.assign(2 * (size_t)max_launches, nullptr);
     g_prof.rec.assign((size_t)max_launches, Rec{0, 0, 0});
     for (auto& e : g_prof.ev)
-        if (hipEventCreate(&e) != hipSuccess) WU_FAIL(-2, "prof_begin: hipEventCreate failed");
+        // timing events: hipEventDisableSystemFence is HIP's flag for events "only being used to measure timing" -- a default event makes
+        // its record a system-scope fence (cache write-back and invalidation, which also slow the work BEHIND it).  Same-box A/B of the
+        // default bench line against --no-roofline: 0.18 ms of overhead per 8.3 ms step with default events, 0.15 with
+        // hipEventReleaseToDevice, 0.07 with this flag (profiles/r03_roofline_overhead.txt)
+        if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) WU_FAIL(-2, "prof_begin: hipEventCreate failed");
     g_prof.mask = family_mask;
     g_prof.used = 0;
     g_prof.open = false;
