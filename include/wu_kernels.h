@@ -60,6 +60,14 @@ int wu_set_option(int key, int value);
  * (DMA wait, compute, whole-kernel s_memtime and s_memrealtime deltas -> in-kernel clock, barrier, epilogue, tiles, chunks);
  * NULL (default) disables stamping. */
 int wu_set_debug_buffer(void* p);
+/* Stream ordering inside one device without a system-scope fence (host plumbing of the fused backward, wu/unet_graph.py: the
+ * weight-gradient hand-offs between its two streams).  wu_stream_order_after(waiter, producer, event): work enqueued on `waiter` after
+ * the call runs after everything enqueued on `producer` before it; `event` (wu_event_create: no timing, hipEventDisableSystemFence) may
+ * be reused for every call.  Nothing in the reference corresponds to this (autograd there runs on one stream). */
+int wu_event_create(void** event_out);
+int wu_event_destroy(void* event);
+int wu_stream_order_after(void* waiter_stream, void* producer_stream, void* event);
+
 /* Experiment support (DIAGNOSTIC): a HIP stream confined to the compute units whose bits are set in mask[0..words) (hipExtStreamCreateWithCUMask),
  * for measuring CU-partitioned overlap of the data-gradient and weight-gradient kernels (scratch/ab_cumask.py); unused by the product path. */
 int wu_stream_create_cu_mask(const unsigned* mask, int words, void** stream_out);

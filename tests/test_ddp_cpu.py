@@ -269,6 +269,9 @@ class _FakeOps:
     def current(self):
         return self.cur[-1]
 
+    def order_after(self, waiter, producer):
+        waiter.wait_stream(producer)
+
     def use(self, stream):
         ops = self
 

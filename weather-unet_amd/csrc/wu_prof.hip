@@ -35,6 +35,28 @@ extern "C" int wu_stream_destroy(void* stream) {
     return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : -1;
 }
 
+// Ordering events between two streams of ONE device: no timing, no system-scope fence.  torch's wait_stream() records a default-flag
+// event: every record is then a system-scope release (write-back towards the host) on the recording stream -- 14 of them per training
+// step on the critical path of the fused backward (one per weight-gradient hand-off).  Kernels on another stream of the same device
+// need device-scope visibility only, which hipEventDisableSystemFence keeps.
+extern "C" int wu_event_create(void** event_out) {
+    WU_REQUIRE(event_out, "event_create: bad args");
+    hipEvent_t e = nullptr;
+    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
+    if (rc != hipSuccess) WU_FAIL((int)rc, "hipEventCreateWithFlags: %s", hipGetErrorString(rc));
+    *event_out = (void*)e;
+    return 0;
+}
+extern "C" int wu_event_destroy(void* event) { return hipEventDestroy((hipEvent_t)event) == hipSuccess ? 0 : -1; }
+// `waiter` will not run work enqueued after this call before everything enqueued on `producer` so far has finished
+extern "C" int wu_stream_order_after(void* waiter, void* producer, void* event) {
+    WU_REQUIRE(event, "stream_order_after: bad args");
+    hipError_t rc = hipEventRecord((hipEvent_t)event, (hipStream_t)producer);
+    if (rc == hipSuccess) rc = hipStreamWaitEvent((hipStream_t)waiter, (hipEvent_t)event, 0);
+    if (rc != hipSuccess) WU_FAIL((int)rc, "stream_order_after: %s", hipGetErrorString(rc));
+    return 0;
+}
+
 // tuning switches (A/B benchmarking of kernel variants inside one process; defaults are the production choices)
 int g_wu_opt[16] = {/*CONV_V2*/ 1, /*CONV_PERSISTENT*/ 1, /*WGRAD_V2*/ 1, /*CONV_CT_SLOWEST*/ 0, /*WGRAD_DMA_INTERLEAVE*/ 1, /*C3_ROWS*/ 0, /*CONV_PRIO*/ 1, /*CONV_STRIDED*/ 1, /*ADAIN_BWD_MARCH*/ 1, /*ADAIN_FWD_MARCH*/ 1, /*GRID_CUS*/ 0, /*CONV_W_RESIDENT*/ 1, /*PW_TILE*/ 0, /*IMG3_TILED*/ 1, 0, 0};
 void* g_wu_dbg_ptr = nullptr;   // diagnostic stamp buffer (256 workgroups x 8 waves x 8 u64), NULL in production

@@ -34,6 +34,9 @@ SIGNATURES = {
     "wu_spectral_norm_scratch_floats": (SZ, [I, I]),
     "wu_spectral_norm_fwd": (I, [P, I, I, P, P, I, F, P, P, P, P]),
     "wu_spectral_norm_bwd": (I, [P, P, P, P, P, P, I, I, P, P]),
+    "wu_event_create": (I, [P]),
+    "wu_event_destroy": (I, [P]),
+    "wu_stream_order_after": (I, [P, P, P]),
     "wu_spectral_norm_fwd_multi": (I, [I, P, P, P, P, P, I, F, P, P, P, P, P, P]),
     "wu_spectral_norm_bwd_multi": (I, [I, P, P, P, P, P, P, P, P, P, P]),
     "wu_pack_conv3x3": (I, [P, P, P, I, I, P, I, P]),
