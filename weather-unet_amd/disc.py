@@ -3,7 +3,7 @@
 4 x (SN-conv3x3 s1 -> SN-conv3x3 s2 -> LeakyReLU 0.2) -> global SUM pool -> SN-Linear(512,1) +
 <SN-Linear(nc,512)(c), feat>.  ``forward(x, c) -> [out(N,1), c1, c2, c3, c4]``; 40 state-dict keys
 (10 SN layers x bias / weight_orig / weight_u / weight_v).  The convs reuse the generator's HIP kernels
-(stride-1/2 MFMA implicit GEMM, LeakyReLU epilogue); the two linear heads are (N,512) GEMVs kept in torch.  All ten spectral
+(stride-1/2 MFMA implicit GEMM, LeakyReLU epilogue); the two linear heads are (N,512) GEMVs (F.linear) on spectrally normalised weights of the same HIP kernels (nets.SNLinear).  All ten spectral
 normalisations of a forward (one power iteration each in training mode, as torch's hooks do) run as ONE batched call before the convs.
 The feature maps c1..c4 are returned as NHWC-strided tensors of the compute dtype (logical NCHW shape).
 """
