@@ -33,6 +33,7 @@ import torch.nn as nn
 import ops
 from cunet import Conditional_UNet
 from disc import SNDisc
+import disc as _disc
 from wu.ddp import GradBucketReducer, broadcast_buffers, is_distributed, ready_order
 
 
@@ -43,6 +44,11 @@ OVERLAP_D_PASSES = os.environ.get("WU_GAN_OVERLAP_D", "1") == "1"
 # with a pass on the second stream, a parameter's AccumulateGrad node (created on the main stream) receives gradients produced on the
 # other one: autograd synchronises the two correctly and says so once per backward (a note about CUDA-graph capture, not an error)
 warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
+
+
+def disc_batched_sn():
+    """SNDisc normalises its ten weights in one batched call at the top of forward (and records SNDisc.sn_done there)."""
+    return _disc.BATCHED_SPECTRAL_NORM
 
 
 class StandInEstimator(nn.Module):
@@ -118,23 +124,28 @@ class WeatherTransferStep:
                 pred_labels = c_d                                                        # :294-295
             elif pred_labels is None:
                 pred_labels = self.estimator(images)                                     # :297
-            fake_out = self.inference(images, labels)                                    # :302-303
-        real_d_out_pred = self.discriminator(images, pred_labels)[0]                     # :299
-        sn_done = getattr(self.discriminator, "sn_done", None)
-        if OVERLAP_D_PASSES and self.d_red is None and images.is_cuda and sn_done is not None:
-            # The pass over the fake batch runs on the second stream beside the pass over the real batch (and so do the two
-            # backward chains): the kernels of one pass at B = 32 leave much of the chip idle.  The only coupling between the passes
-            # is the power-iteration state -- pass 2 iterates the u / v that pass 1's iteration left (disc.py: one iteration per
-            # forward) -- so the second stream starts after the FIRST pass's batched normalisation (SNDisc.sn_done), not after its
-            # convs.  Without a gradient reducer only: its hooks assume one producing stream.
+        if OVERLAP_D_PASSES and self.d_red is None and images.is_cuda and disc_batched_sn():
+            # The pass over the REAL batch needs the images and their labels only: it runs on the second stream, beside the generator's
+            # no-grad forward and then beside the pass over the FAKE batch (the kernels of one pass at B = 32 leave much of the chip
+            # idle; the two backward chains overlap the same way: autograd replays a node on the stream of its forward).  The only
+            # coupling between the passes is the power-iteration state -- the fake pass iterates the u / v the real pass's iteration
+            # left (disc.py: one iteration per forward, real first: t_cls_train.py:299,303) -- so the fake pass waits for the real
+            # pass's batched normalisation (SNDisc.sn_done), not for its convs.  Without a gradient reducer only: its hooks assume one
+            # producing stream.
             main, side = torch.cuda.current_stream(images.device), self._d_stream(images.device)
-            side.wait_event(sn_done)                       # recorded on `main` after G's forward and pass 1's normalisation
-            fake_out.record_stream(side)
+            side.wait_stream(main)                           # the labels' producer, last step's optimizer
             with torch.cuda.stream(side):
-                fake_d_out = self.discriminator(fake_out, labels)[0]
-            fake_d_out.record_stream(main)
+                real_d_out_pred = self.discriminator(images, pred_labels)[0]             # :299
+            real_d_out_pred.record_stream(main)
+            with torch.no_grad():
+                fake_out = self.inference(images, labels)                                # :302-303
+            main.wait_event(self.discriminator.sn_done)      # recorded on `side` after the real pass's normalisation
+            fake_d_out = self.discriminator(fake_out, labels)[0]
             main.wait_stream(side)
         else:
+            with torch.no_grad():
+                fake_out = self.inference(images, labels)                                # :302-303
+            real_d_out_pred = self.discriminator(images, pred_labels)[0]                 # :299
             fake_d_out = self.discriminator(fake_out, labels)[0]
         d_loss = ops.dis_hinge(fake_d_out, real_d_out_pred)                              # :305
         d_loss.backward()
