@@ -665,3 +665,76 @@ def test_tiled_image_conv_beside_the_stem_mfma_kernel():
             torch.cuda.synchronize()
             assert torch.equal(out, ref), f"{name}: differs beside the stem kernel (max {(out - ref).abs().nan_to_num(1e9).max().item():.3e})"
             assert torch.equal(stem_y, stem_ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# encoder sharing between the two generator forwards of one GAN iteration (wu/train_step.py, Conditional_UNet.forward encoder_cache)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_encoder_cache_is_bitwise_neutral():
+    """G(x, c1) under no_grad followed by G(x, c2) with grad -- the reference's two generator forwards of an iteration
+    (t_cls_train.py:302,242), Dropout active with different masks -- give the same outputs and the same 36 parameter gradients
+    bit for bit whether the second forward recomputes the encoder or reuses the first one's (cunet.py:45-54 has no Dropout and does
+    not see the condition)."""
+    import cunet
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = (torch.rand((3, 3, 64, 96), generator=g) * 2 - 1).to(dev)
+    c1 = torch.softmax(torch.randn(3, 5, generator=g), dim=1).to(dev)
+    c2 = torch.softmax(torch.randn(3, 5, generator=g), dim=1).to(dev)
+    gout = torch.randn(3, 3, 64, 96, generator=g).to(dev)
+    torch.manual_seed(8)
+    net = cunet.Conditional_UNet(5, precision="bf16").to(dev).train()
+
+    def run(shared):
+        net.dropout_seed = 11
+        net.zero_grad(set_to_none=True)
+        cache = {} if shared else None
+        with torch.no_grad():
+            o1 = net(x, c1, cache)
+        net.dropout_seed = 12
+        o2 = net(x, c2, cache)
+        o2.backward(gout)
+        if shared:
+            assert cache.get("computed") == 1 and cache.get("reused") == 1
+        return o1.clone(), o2.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert len(a[2]) == 36 and a[2].keys() == b[2].keys()
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    # another input must not hit the cache
+    cache = {}
+    with torch.no_grad():
+        net(x, c1, cache)
+        net(x.clone(), c1, cache)
+    assert cache["computed"] == 2 and "reused" not in cache
+
+
+def test_gan_iteration_with_and_without_encoder_sharing():
+    """A whole GAN iteration (stand-in estimator, every stream overlap on) from identical state with the encoder shared and with
+    it recomputed: the five losses, every G and D gradient and D's power-iteration buffers bit for bit."""
+    from wu import train_step as TS
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(31)
+    x = (torch.rand((4, 3, 64, 64), generator=g) * 2 - 1).to(dev)
+    xr = (torch.rand((4, 3, 64, 64), generator=g) * 2 - 1).to(dev)
+    st = TS.WeatherTransferStep(5, mode="cls", precision="bf16", device=dev, ddp=False, seed=2)
+    for opt in (st.d_opt, st.g_opt):
+        for grp in opt.param_groups:
+            grp["lr"] = 0.0
+            grp["weight_decay"] = 0.0
+    d_state = {k: v.clone() for k, v in st.discriminator.state_dict().items()}
+    res = []
+    try:
+        for share in (True, False, True):
+            TS.SHARE_ENCODER = share
+            res.append(_iteration(st, x, xr, d_state))
+    finally:
+        TS.SHARE_ENCODER = True
+    for other in res[1:]:
+        assert res[0][0] == other[0]
+        for k in res[0][1]:
+            assert torch.equal(res[0][1][k], other[1][k]), k
+        for k in res[0][2]:
+            assert torch.equal(res[0][2][k], other[2][k]), k

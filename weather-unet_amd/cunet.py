@@ -97,13 +97,16 @@ class Conditional_UNet(nn.Module):
             mask_in = pack_keep_mask(self.dropout_masks[3 - k].to(x.device), x.dtype)
         return WF.adain_upcat(x, y_std, y_mean, skip, catbuf, adain.eps, p, self._next_seed(k), self._seed_dev, mask_in)
 
-    def forward(self, x, c):
+    def forward(self, x, c, encoder_cache=None):
+        """``encoder_cache`` (fused graph only; an extension, not in the reference's signature): a dict the caller passes to TWO
+        forwards of the same ``x`` between which the weights do not change -- the encoder (cunet.py:45-54: no Dropout, independent of
+        ``c``) is then computed by the first and reused by the second, bit for bit what two full forwards give."""
         require_cuda(x, "Conditional_UNet")
         n, _, h, w = x.shape
         if h % 8 or w % 8:
             raise ValueError(f"Conditional_UNet: H and W must be divisible by 8 (three 2x poolings), got {h}x{w}")
         if self.fused:
-            return unet_forward(self, x, c)
+            return unet_forward(self, x, c, encoder_cache)
         code = precision_code(self.precision)
         dt, dev = torch_dtype(code), x.device
         c = c.to(device=dev, dtype=torch.float32)

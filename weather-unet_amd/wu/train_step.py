@@ -18,6 +18,10 @@ Differences from the reference loop, all numerically neutral:
     ``rand_images`` (:424) and then twice on the same ``images`` (:297 in update_discriminator, :237 in update_inference), three
     no-grad forwards of a deterministic function of which two are identical; the one call on the concatenated batch returns the
     same numbers (no cross-sample coupling in eval-mode BatchNorm) with half the launches and twice the GEMM rows;
+  * step() computes the generator's ENCODER once per iteration: the reference runs G twice on the same images with the same weights
+    (t_cls_train.py:302 in update_discriminator, :242 in update_inference); the encoder (cunet.py:45-54) has no Dropout and does not see
+    the labels, so both runs compute the same encoder activations bit for bit -- the second forward reuses the first one's and runs the
+    decoder (AdaIN, Dropout with its own masks, up-convs) only; its backward differentiates through the shared activations as usual;
   * evaluation() runs its B transfers as ONE (B*B)-image pass of G / estimator instead of B passes; D joins
     the batched pass in eval mode and runs per pass in train mode (one power iteration per forward, as in the reference);
   * data parallel (new): G and D gradients are averaged by two ``GradBucketReducer``s; the D
@@ -41,6 +45,8 @@ from wu.ddp import GradBucketReducer, broadcast_buffers, is_distributed, ready_o
 OVERLAP_D_WITH_ESTIMATOR = os.environ.get("WU_GAN_OVERLAP", "1") == "1"
 # update_discriminator: the discriminator's real-batch and fake-batch passes on two streams (A/B switch)
 OVERLAP_D_PASSES = os.environ.get("WU_GAN_OVERLAP_D", "1") == "1"
+# step(): the generator's encoder once per iteration instead of twice (A/B switch)
+SHARE_ENCODER = os.environ.get("WU_GAN_SHARE_ENCODER", "1") == "1"
 # with a pass on the second stream, a parameter's AccumulateGrad node (created on the main stream) receives gradients produced on the
 # other one: autograd synchronises the two correctly and says so once per backward (a note about CUDA-graph capture, not an error)
 warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
@@ -112,8 +118,9 @@ class WeatherTransferStep:
         return torch.softmax(y, dim=1) if self.mode == "cls" else y
 
     # ------------------------------------------------------------------ t_cls_train.py:288-312 / t_est_train.py:261-283
-    def update_discriminator(self, images, labels, c_d=None, pred_labels=None):
-        """``pred_labels``: ``self.estimator(images)`` if the caller already has it (step() does); computed here otherwise."""
+    def update_discriminator(self, images, labels, c_d=None, pred_labels=None, encoder_cache=None):
+        """``pred_labels``: ``self.estimator(images)`` if the caller already has it (step() does); computed here otherwise.
+        ``encoder_cache``: step()'s per-iteration dict shared with update_inference (Conditional_UNet.forward)."""
         if self.d_red is not None:
             self.d_red.enabled = True
             self.d_red.zero_grad()
@@ -138,13 +145,13 @@ class WeatherTransferStep:
                 real_d_out_pred = self.discriminator(images, pred_labels)[0]             # :299
             real_d_out_pred.record_stream(main)
             with torch.no_grad():
-                fake_out = self.inference(images, labels)                                # :302-303
+                fake_out = self.inference(images, labels, encoder_cache)                 # :302-303
             main.wait_event(self.discriminator.sn_done)      # recorded on `side` after the real pass's normalisation
             fake_d_out = self.discriminator(fake_out, labels)[0]
             main.wait_stream(side)
         else:
             with torch.no_grad():
-                fake_out = self.inference(images, labels)                                # :302-303
+                fake_out = self.inference(images, labels, encoder_cache)                 # :302-303
             real_d_out_pred = self.discriminator(images, pred_labels)[0]                 # :299
             fake_d_out = self.discriminator(fake_out, labels)[0]
         d_loss = ops.dis_hinge(fake_d_out, real_d_out_pred)                              # :305
@@ -155,7 +162,7 @@ class WeatherTransferStep:
         return d_loss.detach()
 
     # ------------------------------------------------------------------ t_cls_train.py:226-286 / t_est_train.py:214-259
-    def update_inference(self, images, r_labels, d_labels=None, r_labels_=None, pred_labels=None):
+    def update_inference(self, images, r_labels, d_labels=None, r_labels_=None, pred_labels=None, encoder_cache=None):
         if self.g_red is not None:
             self.g_red.zero_grad()
             self.d_red.enabled = False             # D's gradients from this backward are discarded, not reduced
@@ -178,7 +185,7 @@ class WeatherTransferStep:
         # Same kernels, same numbers: the sum into fake_out's gradient follows graph order, not completion order.
         side = self._d_stream(images.device) if OVERLAP_D_WITH_ESTIMATOR and images.is_cuda else None
         try:
-            fake_out = self.inference(images, r_labels)                                  # :242
+            fake_out = self.inference(images, r_labels, encoder_cache)                   # :242
             if side is not None:
                 main = torch.cuda.current_stream(images.device)
                 side.wait_stream(main)
@@ -231,8 +238,11 @@ class WeatherTransferStep:
                 pred_labels = torch.softmax(raw_img, dim=1) if self.mode == "cls" else raw_img
             d_labels = None
             r_idx = (c_r if c_r is not None else torch.argmax(raw, dim=1)) if self.cross_ent else None   # :436,438
-        d_loss = self.update_discriminator(images, rand_labels, d_labels, pred_labels)   # :429
-        g_losses = self.update_inference(images, rand_labels, d_labels, r_idx, pred_labels)   # :432-438
+        # both generator forwards of an iteration see the same images and the same weights (G is updated last): the encoder is computed
+        # by the first and reused by the second (Conditional_UNet.forward, encoder_cache)
+        enc = {} if SHARE_ENCODER and getattr(self.inference, "fused", False) else None
+        d_loss = self.update_discriminator(images, rand_labels, d_labels, pred_labels, enc)   # :429
+        g_losses = self.update_inference(images, rand_labels, d_labels, r_idx, pred_labels, enc)   # :432-438
         return (d_loss,) + g_losses
 
     # ------------------------------------------------------------------ t_cls_train.py:314-367 / t_est_train.py:285-332

@@ -170,7 +170,7 @@ def _new(n, c, h, w, dt, dev):
 class UNetFn(Function):
     @staticmethod
     def forward(ctx, meta, x, ys3, ym3, ys2, ym2, ys1, ym1, *params):
-        code, p_drop, seeds, eps, packed, sink, inj, seed_dev = meta
+        code, p_drop, seeds, eps, packed, sink, inj, seed_dev, enc_cache = meta
         inj = inj if inj is not None else (None, None, None)
         dt, dev = torch_dtype(code), x.device
         if x.dtype != torch.float32 or not x.is_contiguous():
@@ -194,10 +194,25 @@ class UNetFn(Function):
                 pk[name + ".0"] = packed[2 * i].get(w0, code)
             pk[name + ".2"] = packed[2 * i + 1].get(w2, code)
         want_bits = any(ctx.needs_input_grad)
+        # Encoder sharing (wu/train_step.py): the encoder (cunet.py:45-54) has no Dropout and does not see the condition, so two forwards
+        # of the SAME input with the SAME weights -- the generator's no-grad pass of the discriminator update and its pass of the
+        # generator update, t_cls_train.py:302,242 -- compute identical encoder activations.  With a cache dict from the caller the first
+        # forward keeps them (with gate bits, whatever its grad mode: the second one differentiates through them) and the second reuses
+        # them: its decoder overwrites the upsampled halves of the same concat buffers.  The caller vouches that input and weights are
+        # unchanged in between; a shape / pointer mismatch recomputes.
+        enc = None
+        if enc_cache is not None:
+            enc = enc_cache.get("state")
+            if enc is not None and enc["key"] != (x.data_ptr(), x._version, tuple(x.shape), code):
+                enc = None
+        enc_bits = want_bits or enc_cache is not None
 
-        cat1 = _new(n, 192, h, w, dt, dev)
-        cat2 = _new(n, 384, h // 2, w // 2, dt, dev)
-        cat3 = _new(n, 768, h // 4, w // 4, dt, dev)
+        if enc is None:
+            cat1 = _new(n, 192, h, w, dt, dev)
+            cat2 = _new(n, 384, h // 2, w // 2, dt, dev)
+            cat3 = _new(n, 768, h // 4, w // 4, dt, dev)
+        else:
+            cat1, cat2, cat3 = enc["cat"]
         conv1, conv2, conv3 = cat1[:, 128:], cat2[:, 256:], cat3[:, 512:]
 
         # The ReLU gate of every block's first conv output ("mid") is needed once more, by the data-gradient pass of the block's
@@ -205,28 +220,37 @@ class UNetFn(Function):
         # epilogue reads one dword per lane and row instead of the tensor (wu_kernels.h, "gate bits").
         gbits = {}
 
-        def mid_conv(name, xin, out):
+        def mid_conv(name, xin, out, bits=None):
             """First conv of block `name`: conv + bias + ReLU, with gate bits when wanted and supported."""
-            if GATE_BITS and want_bits and K.gate_bits_supported(xin, out):
+            if GATE_BITS and (want_bits if bits is None else bits) and K.gate_bits_supported(xin, out):
                 gbits[name] = K.gate_bits_alloc(out)
                 return K.conv3x3_bits(xin, pk[name + ".0"][0], wb[name][1], out, RELU, gate_bits_out=gbits[name])
             return K.conv3x3(xin, pk[name + ".0"][0], wb[name][1], out, 1, RELU)
 
         # ---- encoder (cunet.py:45-54) ----
         w_first = wb["dconv_down1"][0].detach().contiguous()
-        a1 = _new(n, 64, h, w, dt, dev)
-        if GATE_BITS and want_bits and K.conv3x3_c3_bits_supported(x, w_first, wb["dconv_down1"][1], 1, code) and K.gate_bits_supported(a1, a1):
-            gbits["dconv_down1"] = K.gate_bits_alloc(a1)
-            K.conv3x3_c3_bits(x, w_first, wb["dconv_down1"][1], a1, gbits["dconv_down1"], 1, code)
+        if enc is None:
+            a1 = _new(n, 64, h, w, dt, dev)
+            if GATE_BITS and enc_bits and K.conv3x3_c3_bits_supported(x, w_first, wb["dconv_down1"][1], 1, code) and K.gate_bits_supported(a1, a1):
+                gbits["dconv_down1"] = K.gate_bits_alloc(a1)
+                K.conv3x3_c3_bits(x, w_first, wb["dconv_down1"][1], a1, gbits["dconv_down1"], 1, code)
+            else:
+                K.conv3x3_c3(x, w_first, wb["dconv_down1"][1], a1, 1, RELU, False, code)
+            p1 = K.conv3x3_relu_pool(a1, pk["dconv_down1.2"][0], wb["dconv_down1"][3], conv1, _new(n, 64, h // 2, w // 2, dt, dev))[1]
+            a2 = mid_conv("dconv_down2", p1, _new(n, 128, h // 2, w // 2, dt, dev), enc_bits)
+            p2 = K.conv3x3_relu_pool(a2, pk["dconv_down2.2"][0], wb["dconv_down2"][3], conv2, _new(n, 128, h // 4, w // 4, dt, dev))[1]
+            a3 = mid_conv("dconv_down3", p2, _new(n, 256, h // 4, w // 4, dt, dev), enc_bits)
+            p3 = K.conv3x3_relu_pool(a3, pk["dconv_down3.2"][0], wb["dconv_down3"][3], conv3, _new(n, 256, h // 8, w // 8, dt, dev))[1]
+            a4 = mid_conv("dconv_down4", p3, _new(n, 512, h // 8, w // 8, dt, dev), enc_bits)
+            b4 = K.conv3x3(a4, pk["dconv_down4.2"][0], wb["dconv_down4"][3], _new(n, 512, h // 8, w // 8, dt, dev), 1, RELU)
+            if enc_cache is not None:
+                enc_cache["state"] = {"key": (x.data_ptr(), x._version, tuple(x.shape), code), "cat": (cat1, cat2, cat3),
+                                      "act": (a1, p1, a2, p2, a3, p3, a4, b4), "gbits": dict(gbits)}
+                enc_cache["computed"] = enc_cache.get("computed", 0) + 1
         else:
-            K.conv3x3_c3(x, w_first, wb["dconv_down1"][1], a1, 1, RELU, False, code)
-        p1 = K.conv3x3_relu_pool(a1, pk["dconv_down1.2"][0], wb["dconv_down1"][3], conv1, _new(n, 64, h // 2, w // 2, dt, dev))[1]
-        a2 = mid_conv("dconv_down2", p1, _new(n, 128, h // 2, w // 2, dt, dev))
-        p2 = K.conv3x3_relu_pool(a2, pk["dconv_down2.2"][0], wb["dconv_down2"][3], conv2, _new(n, 128, h // 4, w // 4, dt, dev))[1]
-        a3 = mid_conv("dconv_down3", p2, _new(n, 256, h // 4, w // 4, dt, dev))
-        p3 = K.conv3x3_relu_pool(a3, pk["dconv_down3.2"][0], wb["dconv_down3"][3], conv3, _new(n, 256, h // 8, w // 8, dt, dev))[1]
-        a4 = mid_conv("dconv_down4", p3, _new(n, 512, h // 8, w // 8, dt, dev))
-        b4 = K.conv3x3(a4, pk["dconv_down4.2"][0], wb["dconv_down4"][3], _new(n, 512, h // 8, w // 8, dt, dev), 1, RELU)
+            a1, p1, a2, p2, a3, p3, a4, b4 = enc["act"]
+            gbits.update(enc["gbits"])
+            enc_cache["reused"] = enc_cache.get("reused", 0) + 1
 
         # ---- decoder (cunet.py:59-78): adain -> upsample -> dropout -> cat fused, then r_double_conv ----
         ys = [t.detach().float().contiguous() for t in (ys3, ys2, ys1)]
@@ -364,8 +388,9 @@ class UNetFn(Function):
         return (None, dx, dys3, dym3, dys2, dym2, dys1, dym1, *flat)
 
 
-def unet_forward(net, x, c):
-    """Run ``Conditional_UNet`` `net` through the fused graph (called by its forward)."""
+def unet_forward(net, x, c, encoder_cache=None):
+    """Run ``Conditional_UNet`` `net` through the fused graph (called by its forward).  ``encoder_cache``: a dict shared by two forwards
+    of the same input with unchanged weights -- the second reuses the first one's encoder activations (UNetFn.forward)."""
     code = precision_code(net.precision)
     c = c.to(device=x.device, dtype=torch.float32)
     styles = []
@@ -386,5 +411,5 @@ def unet_forward(net, x, c):
         dt = torch_dtype(code)
         inj = tuple(K.pack_keep_mask(m.to(x.device), dt) for m in net.dropout_masks)
     meta = (code, float(p), seeds, float(net.adain3.eps), packed, getattr(net, "grad_sink", None), inj,
-            getattr(net, "_seed_dev", None))
+            getattr(net, "_seed_dev", None), encoder_cache)
     return UNetFn.apply(meta, x, *styles, *params)
