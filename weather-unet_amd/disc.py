@@ -75,6 +75,7 @@ class SNDisc(nn.Module):
         iteration per layer in training mode, buffers updated in place), handed to the layers for their next forward; the packed
         MFMA operands of the six wide convs are rebuilt in one launch as well."""
         layers = self.sn_layers()
+        self.sn_batched_last = False                         # did THIS forward normalise in one batched call (and record sn_done)?
         if not BATCHED_SPECTRAL_NORM or len({m.training for m in layers}) != 1 or len({m.eps for m in layers}) != 1 or not layers[0].weight_orig.is_cuda:
             return []                                        # mixed modes / CPU: every layer normalises its own weight
         train = layers[0].training
@@ -84,6 +85,7 @@ class SNDisc(nn.Module):
         if ev is None:
             ev = _SN_DONE[self] = torch.cuda.Event()
         ev.record()                                          # the power-iteration buffers are final for this forward (wu/train_step.py)
+        self.sn_batched_last = True
         for m, w in zip(layers, w_eff):
             if train:
                 m._sn_generation += 1

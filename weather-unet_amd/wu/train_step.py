@@ -146,7 +146,10 @@ class WeatherTransferStep:
             real_d_out_pred.record_stream(main)
             with torch.no_grad():
                 fake_out = self.inference(images, labels, encoder_cache)                 # :302-303
-            main.wait_event(self.discriminator.sn_done)      # recorded on `side` after the real pass's normalisation
+            if getattr(self.discriminator, "sn_batched_last", False):
+                main.wait_event(self.discriminator.sn_done)  # recorded on `side` after the real pass's normalisation
+            else:                                            # per-layer normalisation (mixed modes): the whole real pass first
+                main.wait_stream(side)
             fake_d_out = self.discriminator(fake_out, labels)[0]
             main.wait_stream(side)
         else:
