@@ -54,7 +54,8 @@ int wu_cu_count(void);
  *   9: marching AdaIN-upsample forward (default 1)
  *   10: persistent-grid size override in compute units (0 = the device's count; experiments on CU-masked streams)
  *   11: Cin = 64 / one-cout-tile convs keep both weight chunks resident in LDS across a workgroup's tiles (default 1)
- *   12: pointwise-GEMM pixel tile (0 = 64 rows (default), 1 = 256 rows, 2 = 128 rows) */
+ *   12: pointwise-GEMM pixel tile (0 = 64 rows (default), 1 = 256 rows, 2 = 128 rows)
+ *   13: image-layout 3 -> 3 conv (SNDisc's first layer): 1 = LDS-tiled kernels (default), 0 = one thread per pixel */
 int wu_set_option(int key, int value);
 /* Diagnostic: device buffer of 256*8*8 uint64 receiving per-wave phase cycle sums of the persistent conv / wgrad kernels
  * (DMA wait, compute, whole-kernel s_memtime and s_memrealtime deltas -> in-kernel clock, barrier, epilogue, tiles, chunks);
