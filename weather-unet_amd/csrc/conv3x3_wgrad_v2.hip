@@ -110,7 +110,7 @@ __device__ __forceinline__ void compute_tile(const char* lds, const int (&a_lane
             if (g + 1 < NG && i == 1) af[(g + 1) & 1][0] = load_a(g + 1, 0);
             if (g + 1 < NG && i == 2) af[(g + 1) & 1][1] = load_a(g + 1, 1);
             __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of this step's MFMAs
-            if (i < 4) {
+            if constexpr (i < 4) {
                 mma(acc[2 * i], af[g & 1][0], b);
                 mma(acc[2 * i + 1], af[g & 1][1], b);
             } else {
@@ -121,7 +121,7 @@ __device__ __forceinline__ void compute_tile(const char* lds, const int (&a_lane
             mma(acc[i < 4 ? 2 * i : 8], af[g & 1][i < 4 ? 0 : HF], b);
             if (s_ + LA < NS) bf[(s_ + LA) % (LA + 1)] = load_b(s_ + LA);
             __builtin_amdgcn_sched_barrier(0);
-            if (i < 4) mma(acc[2 * i + 1], af[g & 1][1], b);
+            if constexpr (i < 4) mma(acc[2 * i + 1], af[g & 1][1], b);
             if (g + 1 < NG && i == 1) af[(g + 1) & 1][0] = load_a(g + 1, 0);
             if (g + 1 < NG && i == 2) af[(g + 1) & 1][1] = load_a(g + 1, 1);
             if (i == 0) issue(g);
