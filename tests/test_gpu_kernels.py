@@ -325,6 +325,9 @@ def test_adain_upcat_bwd_mask_bits_vs_rehash(p):
     keep_frac = sum(bin(int(b)).count("1") for b in bits[:4096].cpu().tolist()) / (4096 * (16 // esz))
     assert abs(keep_frac - 0.7) < 0.03
     res = []
+    # both runs on the MARCHING kernel (option 8 = 5): the LDS-ring kernel of round 4 needs stored bits, and its per-(n, c) partial sums
+    # are grouped by other tiles (tests/test_gpu_round4.py compares it with this one)
+    _lib.call("wu_set_option", 8, 5)
     for mb in (bits.data_ptr(), None):
         dx = empty_nhwc(n, c, h, w, _tdt(p), _dev())
         dstd, dmean = torch.empty((n, c), device=_dev()), torch.empty((n, c), device=_dev())
@@ -334,6 +337,7 @@ def test_adain_upcat_bwd_mask_bits_vs_rehash(p):
                   dx.data_ptr(), nhwc_ld(dx), dstd.data_ptr(), dmean.data_ptr(), gtmp.data_ptr(), sums.data_ptr(),
                   n, h, w, c, 0.3, seed, mb, 0, code, s)
         res.append((dx.clone(), dstd.clone(), dmean.clone()))
+    _lib.call("wu_set_option", 8, 1)
     for a, b in zip(*res):
         assert torch.equal(a, b)
 
@@ -451,7 +455,7 @@ def test_adain_upcat_bwd_marching_vs_gather(p):
     res = {}
     try:
         for mode in (0, 1):
-            _lib.call("wu_set_option", 8, mode)
+            _lib.call("wu_set_option", 8, 5 if mode == 1 else 0)      # 5 = the marching kernel also where the LDS-ring kernel would run
             for bits in (mb, None):
                 dx = empty_nhwc(n, c, h, w, _tdt(p), _dev())
                 ds, dm = K.adain_upcat_bwd(g, x, stats, ystd, dx, 0.3, seed, bits, 1)

@@ -629,8 +629,9 @@ def test_tiled_image_conv_beside_the_stem_mfma_kernel():
     """Regression test for the cross-stream hazard of DESIGN.md 4: the LDS-tiled image-layout 3 -> 3 conv (forward and its
     transposed-weight data-gradient form) must give bit-identical results when it runs on a second stream BESIDE the stem's MFMA
     kernel (the arrangement of WeatherTransferStep.update_inference: D's first conv beside the estimator's stem).  With packed-FP32
-    FMAs in the kernel 10 of 10 launches came back with a few wrong 16-lane groups; a blocker on the main stream makes the two
-    kernels start together."""
+    FMAs in the kernel 10 of 10 launches came back with a few wrong 16-lane groups (round 4's discriminating run, profiles/r04_hazard.txt:
+    every v_pk_fma_f32 form fails whatever its LDS-read queue, every scalar-FMA form is exact); a blocker on the main stream makes the two
+    kernels start together.  Round 4: the weight-gradient form (img3_wgrad_kernel) is covered too."""
     from wu import _lib, kernels as K, resnet as RN
     from wu.layout import empty_nhwc
     from wu.unet_graph import _side_stream
@@ -644,17 +645,25 @@ def test_tiled_image_conv_beside_the_stem_mfma_kernel():
     bs = (torch.rand(64, generator=g) - 0.5).to(dev)
     stem_y = empty_nhwc(B, 64, S // 2, S // 2, torch.bfloat16, dev)
     main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-    subjects = {"forward": lambda out: K.conv3x3_c3(x, w33, b3, out, 1, 0, True, code),
-                "data gradient": lambda out: K.conv3x3_c3_dgrad(x, w33, out, 1, code, dy_nchw=True)}
+    gy3 = (torch.rand((B, 3, S, S), generator=g) - 0.5).to(dev)
+
+    def wgrad(out):
+        # img3_wgrad_kernel (81 + 3 accumulators per thread over a grid-stride loop of tiles): dW in out[:81], dbias in out[81:84]
+        K.conv3x3_c3_wgrad(x, gy3, out[:81].view(3, 3, 3, 3), out[81:84], 1, code, dy_nchw=True)
+
+    subjects = {"forward": (lambda out: K.conv3x3_c3(x, w33, b3, out, 1, 0, True, code), lambda: torch.full_like(x, float("nan"))),
+                "data gradient": (lambda out: K.conv3x3_c3_dgrad(x, w33, out, 1, code, dy_nchw=True), lambda: torch.full_like(x, float("nan"))),
+                "weight gradient": (wgrad, lambda: torch.full((84,), float("nan"), device=dev))}
     RN.stem7x7(x, ws, bs, stem_y, 1, code)
     torch.cuda.synchronize()
     stem_ref = stem_y.clone()
-    for name, subj in subjects.items():
-        ref = torch.empty_like(x)
+    for name, (subj, fresh) in subjects.items():
+        ref = fresh()
         subj(ref)
         torch.cuda.synchronize()
+        assert not ref.isnan().any()
         for _ in range(6):
-            out = torch.full_like(x, float("nan"))
+            out = fresh()
             torch.cuda.synchronize()
             torch.cuda._sleep(3_000_000)
             side.wait_stream(main)

@@ -67,3 +67,39 @@ def test_c3_forward_prefetch_registers_are_not_read_before_the_wait(tmp_path):
                         raise AssertionError(f"{text[st][:70]}...: `{body[i].strip()}` reads {reg} before the wait (load at +{at}, wait at +{wait})")
         checked += 1
     assert checked == len(starts)
+
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+LIB = os.path.join(ROOT, "weather-unet_amd", "lib", "libwu_kernels.so")
+
+
+def _device_disassembly(tmp_path):
+    """Disassembly of every gfx950 code object bundled in the built library (one per source file)."""
+    import shutil
+    work = tmp_path / "lib"
+    work.mkdir()
+    so = str(work / "libwu_kernels.so")
+    shutil.copy(LIB, so)                                             # --offloading extracts next to its input
+    subprocess.run([OBJDUMP, "--offloading", so], check=True, capture_output=True, timeout=300)
+    objs = sorted(str(p) for p in work.iterdir() if "amdgcn-amd-amdhsa--gfx950" in p.name)
+    assert objs, "no gfx950 code object found in libwu_kernels.so"
+    out = []
+    for o in objs:
+        out.append(subprocess.run([OBJDUMP, "-d", o], check=True, capture_output=True, text=True, timeout=600).stdout)
+    return objs, "\n".join(out)
+
+
+@pytest.mark.skipif(not (os.path.exists(OBJDUMP) and os.path.exists(LIB)), reason="needs llvm-objdump and the built library")
+def test_library_has_no_packed_fp32_valu_ops(tmp_path):
+    """The guard of DESIGN.md 4 (cross-stream hazard): round 4's discriminating run (profiles/r04_hazard.txt) pinned the corruption of the
+    tiled image conv beside the stem's MFMA kernel on the PACKED-FP32 VALU instructions -- every form with v_pk_fma_f32 failed 10 of 10
+    whatever its LDS-read queue, every form without was exact, fmaf under -packed-fp32-ops with a deep counted-wait queue included.  Any
+    kernel of this library can end up beside an MFMA kernel on a second stream (the GAN step overlaps D with G and with the estimator), so
+    NO code object may contain the instruction class; checked on the machine code that ships, every kernel."""
+    from wu import _build
+    assert not _build.is_stale(), "libwu_kernels.so was not built from the sources in the tree (run __graft_entry__.build())"
+    objs, text = _device_disassembly(tmp_path)
+    assert len(objs) >= 10 and text.count("s_endpgm") > 100          # the whole library was looked at
+    bad = [l.strip() for l in text.splitlines() if re.search(r"\bv_pk_(fma|mul|add)_f32\b", l)]
+    assert not bad, f"{len(bad)} packed-FP32 VALU instructions in the shipped library, e.g. {bad[:3]}"
+    assert "v_mfma_f32_32x32x16_bf16" in text and "buffer_load_dwordx4" in text      # sanity: this IS the device code

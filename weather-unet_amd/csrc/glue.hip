@@ -748,6 +748,227 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_march_kernel(
     block_reduce_2x64<PP>(red, tid, sums + (((size_t)n * C + cg * 64) * splits + blockIdx.y) * 2, splits * 2);
 }
 
+// backward stage A, third formulation (round 4, bf16): the strip is STREAMED THROUGH AN LDS RING by LDS-DMA.
+// The marching kernel above is bound by what a wave keeps in flight, not by bytes (3 TB/s; SQ_WAIT_ANY 58-62 %: one high-res row of
+// 4-6 register loads per thread, retired with vmcnt(0) every row).  Here a workgroup (8 chunk lanes x 32 low-res columns) owns a
+// (64-channel, 32-column, row-strip) tile and walks it in STEPS of two high-res rows; a step's operands -- two 66-pixel x 128-byte dy
+// rows, their keep bytes, one 32-pixel row of x -- are fetched D = 2 steps ahead by `buffer_load ... lds` (28 wave instructions per
+// step, 7 per wave, every one a full-line coalesced piece; no staging registers, nothing the compiler waits for), so 2 x 22 KiB per
+// workgroup and ~90 KiB per CU are always in flight.  One barrier per step; the arithmetic (horizontal 4-tap reduce with
+// row-independent weights, two-term vertical blend, per-(n,c) sums in fp32 before the bf16 rounding of g') is the marching kernel's,
+// term for term in the same order.
+//   step slot (22 528 B) = 2 x { main 64 px x 128 B, swizzled | halo px -1 and 64 (256 B) | keep bytes 66 px x 8 (768 B) } + x row 4 KiB
+//   pixel p of the main window sits at slot p ^ ((p >> 1) & 1): the 16-lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS) then
+//   see the eight chunk lanes of four columns on four different 64-byte bank quarters (the swizzle is applied to the DMA SOURCE).
+// Low-res row yy is complete when high-res row 2 yy + 3 arrives (scale (H-1)/(2H-1) < 1/2), i.e. in step yy - xbase with
+// xbase = (r_begin >> 1) - 1: that step's slot carries x row yy; the last row(s) of a strip are emitted after the loop from the
+// slot of the extra step that only brings x.
+namespace upbt {
+constexpr int TC = 32;                                             // low-res columns per workgroup
+constexpr int ROW_MAIN = 8192, ROW_HALO = 256, ROW_MASK = 768;
+constexpr int ROW_BYTES = ROW_MAIN + ROW_HALO + ROW_MASK;          // 9216
+constexpr int X_BYTES = TC * 128;                                  // 4096
+constexpr int STEP_BYTES = 2 * ROW_BYTES + X_BYTES;                // 22528
+constexpr int D = 2, RS = D + 1;                                   // steps in flight, ring slots
+constexpr int NPIECE = 7;                                          // DMA instructions per wave and step
+constexpr int LUT_OFF = RS * STEP_BYTES;                           // 67584
+constexpr int SMEM = LUT_OFF + 4096;                               // 71680 B: two workgroups per CU
+}  // namespace upbt
+
+__global__ __launch_bounds__(256) void adain_upcat_bwd_tile_kernel(
+    const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx, const float* __restrict__ stats,
+    bf16_t* __restrict__ gtmp, float* __restrict__ sums, int H, int W, int C, int rows_per_strip, int col_tiles,
+    float sy, float sx, uint32_t thr, float keep_scale, const uint8_t* __restrict__ mbits) {
+    using namespace upbt;
+    constexpr int E = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool masked = thr < 0x10000u;
+    if (masked) {
+        uint32_t m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = ((tid >> (2 * k)) & 1 ? 0x0000ffffu : 0u) | ((tid >> (2 * k + 1)) & 1 ? 0xffff0000u : 0u);
+        *(uint4*)(smem + LUT_OFF + tid * 16) = make_uint4(m[0], m[1], m[2], m[3]);
+    }
+    const int cg = blockIdx.x, n = blockIdx.z;
+    const int ctile = blockIdx.y % col_tiles, strip = blockIdx.y / col_tiles;
+    const int cl = tid & 7, pl = tid >> 3;
+    const int c0 = cg * 64 + cl * E;
+    const int cpp = C >> 3;
+    const int H2 = 2 * H, W2 = 2 * W, HW = H * W;
+    const int x0t = ctile * TC, xx = x0t + pl;
+    const int y0 = strip * rows_per_strip, y1 = min(H, y0 + rows_per_strip);
+    const int r_begin = max(0, 2 * y0 - 1), r_end = min(H2 - 1, 2 * y1);
+    const int nsteps = (r_end - r_begin + 2) >> 1;          // pairs of high-res rows
+    const int total = nsteps + 1;                           // + the step that only carries the last x row
+    const int xbase = (r_begin >> 1) - 1;                   // step s carries x row xbase + s
+
+    // ---- tile-invariant per-lane DMA source offsets (bytes; kWuOOB = this lane fetches nothing and lands zeros) ----
+    // dy descriptor: one image, shifted back by ONE pixel so that the left halo column has a non-negative offset
+    unsigned vo_main[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = (wave + 4 * j) * 64 + lane, pp = i >> 3, c = i & 7;
+        const int p = pp ^ ((pp >> 1) & 1);
+        vo_main[j] = 2 * x0t + p < W2 ? (unsigned)(((p + 1) * lddy + cg * 64 + c * 8) * 2) : kWuOOB;
+    }
+    // third piece of a row: wave 0 the two halo pixels (dword lanes: 32 per pixel), waves 1-3 the keep bytes (dword lanes: 2 per pixel)
+    unsigned vo_c;
+    if (wave == 0) {
+        const int h = lane >> 5, col = h ? 2 * x0t + 64 : 2 * x0t - 1;
+        vo_c = (col >= 0 && col < W2) ? (unsigned)(((h ? 65 : 0) * lddy + cg * 64) * 2 + (lane & 31) * 4) : kWuOOB;
+    } else {
+        const int dd = (wave - 1) * 64 + lane;
+        if (dd < 128) {
+            const int p = dd >> 1;
+            vo_c = 2 * x0t + p < W2 ? (unsigned)((p + 1) * cpp + cg * 8 + (dd & 1) * 4) : kWuOOB;
+        } else if (dd < 132) {
+            const int h = (dd - 128) >> 1, col = h ? 2 * x0t + 64 : 2 * x0t - 1;
+            vo_c = (col >= 0 && col < W2) ? (unsigned)((h ? 65 : 0) * cpp + cg * 8 + (dd & 1) * 4) : kWuOOB;
+        } else {
+            vo_c = kWuOOB;
+        }
+    }
+    unsigned vo_x;
+    {
+        const int i = wave * 64 + lane, px = i >> 3, c = i & 7;
+        vo_x = x0t + px < W ? (unsigned)((px * ldx + cg * 64 + c * 8) * 2) : kWuOOB;
+    }
+    const wu_rsrc_t rs_d = wu_make_rsrc(dy + ((long long)n * H2 * W2 - 1) * lddy, (unsigned)(((size_t)H2 * W2 + 1) * lddy * 2));
+    const wu_rsrc_t rs_m = wu_make_rsrc(mbits ? mbits + ((long long)n * H2 * W2 - 1) * cpp : nullptr,
+                                        (masked && mbits) ? (unsigned)(((size_t)H2 * W2 + 1) * cpp) : 0u);
+    const wu_rsrc_t rs_x = wu_make_rsrc(x + (size_t)n * HW * ldx, (unsigned)((size_t)HW * ldx * 2));
+    const wu_rsrc_t rs_c = wave == 0 ? rs_d : rs_m;
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned c_lds = wave == 0 ? (unsigned)ROW_MAIN : (unsigned)(ROW_MAIN + ROW_HALO + (wave - 1) * 256);
+
+    auto issue = [&](int j, int slot) __attribute__((always_inline)) {       // the 7 pieces of step j (wave-uniform arguments)
+        const unsigned lds = smem_base + slot * STEP_BYTES;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = r_begin + 2 * j + rr;
+            const unsigned kill = r > r_end ? kWuOOB : 0u;
+            const unsigned pix = (unsigned)(r * W2 + 2 * x0t);
+            const unsigned so_d = (pix * (unsigned)lddy * 2u) | kill;
+            const unsigned so_c = (wave == 0 ? pix * (unsigned)lddy * 2u : pix * (unsigned)cpp) | kill;
+            const unsigned row = lds + rr * ROW_BYTES;
+            wu_dma16b(vo_main[0], rs_d, __builtin_amdgcn_readfirstlane(so_d), __builtin_amdgcn_readfirstlane(row + wave * 1024));
+            wu_dma16b(vo_main[1], rs_d, __builtin_amdgcn_readfirstlane(so_d), __builtin_amdgcn_readfirstlane(row + (wave + 4) * 1024));
+            wu_dma4b(vo_c, rs_c, __builtin_amdgcn_readfirstlane(so_c), __builtin_amdgcn_readfirstlane(row + c_lds));
+        }
+        const int xr = xbase + j;
+        const unsigned so_x = (xr >= y0 && xr < y1) ? (unsigned)((xr * W + x0t) * ldx * 2) : kWuOOB;
+        wu_dma16b(vo_x, rs_x, __builtin_amdgcn_readfirstlane(so_x), __builtin_amdgcn_readfirstlane(lds + 2 * ROW_BYTES + wave * 1024));
+    };
+
+    // ---- per-thread LDS read offsets inside a row / step slot, column weights ----
+    int daddr[4], maddr[4];
+    float wgt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = 2 * pl - 1 + k;                                      // pixel of the main window; -1 / 64 = the halo pixels
+        daddr[k] = q < 0 ? ROW_MAIN + cl * 16 : q >= 64 ? ROW_MAIN + 128 + cl * 16 : (q ^ ((q >> 1) & 1)) * 128 + cl * 16;
+        maddr[k] = ROW_MAIN + ROW_HALO + (q < 0 ? 512 + cl : q >= 64 ? 520 + cl : q * 8 + cl);
+        const int j = 2 * xx - 1 + k;
+        const int jc = min(max(j, 0), W2 - 1);
+        const Lerp lx = src_index(jc, sx, W);
+        wgt[k] = j == jc ? ((lx.i0 == xx ? lx.l0 : 0.f) + (lx.i1 == xx ? lx.l1 : 0.f)) : 0.f;
+    }
+    const int xaddr = 2 * ROW_BYTES + pl * 128 + cl * 16;
+
+    float st[2 * E];
+    ldf<2 * E>(stats + 2 * (n * C + c0), st);
+    // the statistics are in registers BEFORE the first DMA is issued: a compiler-inserted vmcnt(0) for them inside the loop would
+    // drain the ring at every emit (the compiler does not see the DMA; its waits retire in issue order)
+#pragma unroll
+    for (int e = 0; e < 2 * E; ++e) asm volatile("" : "+v"(st[e]));
+
+    issue(0, 0);
+    if (total > 1) issue(1, 1);
+
+    float s1[E], s2[E], acc0[E], acc1[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) s1[e] = s2[e] = acc0[e] = acc1[e] = 0.f;
+    int cur = src_index(r_begin, sy, H).i0;
+
+    auto emit = [&](int yy, const float (&ga)[E]) __attribute__((always_inline)) {
+        if (yy < y0 || yy >= y1) return;
+        const int e_ = yy - xbase;                                         // the step whose slot carries x row yy
+        const int slot = e_ - 3 * (e_ / 3);
+        float xv[E], gs[E];
+        unpack16<bf16_t>(*(const uint4*)(smem + slot * STEP_BYTES + xaddr), xv);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            gs[e] = masked ? ga[e] * keep_scale : ga[e];
+            if (xx < W) {
+                s1[e] += gs[e];
+                s2[e] += gs[e] * ((xv[e] - st[2 * e]) * st[2 * e + 1]);
+            }
+        }
+        if (xx < W) *(uint4*)(gtmp + ((size_t)n * HW + (size_t)yy * W + xx) * C + c0) = pack16<bf16_t>(gs);
+    };
+
+    int slot = 0;                                                          // ring slot of the step being computed
+    for (int s = 0; s < total; ++s) {
+        // this wave's pieces of step s have landed: everything issued after them is step s + 1's 7 pieces (and stores, which are
+        // younger still) -- vmcnt retires in issue order
+        if (s + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                   // ... everyone's have; everyone is done with step s - 1's slot
+        if (s + D < total) issue(s + D, slot == 0 ? 2 : slot - 1);         // (s + 2) % 3 == (s - 1) % 3
+        if (s < nsteps) {
+            const char* sl = smem + slot * STEP_BYTES;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = r_begin + 2 * s + rr;
+                if (r > r_end) break;
+                const Lerp ly = src_index(r, sy, H);
+                while (cur < ly.i0) {                                      // retire the rows no later high-res row can touch
+                    emit(cur, acc0);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) { acc0[e] = acc1[e]; acc1[e] = 0.f; }
+                    ++cur;
+                }
+                const char* row = sl + rr * ROW_BYTES;
+                float t[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) t[e] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint4 dv = *(const uint4*)(row + daddr[k]);
+                    if (masked) {
+                        const uint4 mk = *(const uint4*)(smem + LUT_OFF + 16 * (unsigned)*(const uint8_t*)(row + maddr[k]));
+                        dv = make_uint4(dv.x & mk.x, dv.y & mk.y, dv.z & mk.z, dv.w & mk.w);
+                    }
+                    float d[E];
+                    unpack16<bf16_t>(dv, d);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) t[e] = fmaf(wgt[k], d[e], t[e]);
+                }
+                const float l1w = ly.i1 != ly.i0 ? ly.l1 : 0.f, l0w = ly.i1 != ly.i0 ? ly.l0 : ly.l0 + ly.l1;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    acc0[e] = fmaf(l0w, t[e], acc0[e]);
+                    acc1[e] = fmaf(l1w, t[e], acc1[e]);
+                }
+            }
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    emit(cur, acc0);
+    emit(cur + 1, acc1);
+    __syncthreads();                                                       // the ring becomes the reduction scratch
+    float (*red)[64][2] = (float (*)[64][2])smem;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        red[pl][cl * E + e][0] = s1[e];
+        red[pl][cl * E + e][1] = s2[e];
+    }
+    const int splits = gridDim.y;
+    block_reduce_2x64<TC>(red, tid, sums + (((size_t)n * C + cg * 64) * splits + blockIdx.y) * 2, splits * 2);
+}
+
 // fold the per-split partials in fixed order: sums_final[n][c][2]
 __global__ void fold_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int NC2, int splits) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -792,6 +1013,62 @@ __global__ __launch_bounds__(256) void adain_upcat_bwd_apply_kernel(const T* __r
             }
         }
         *(uint4*)(dx + p * lddx + ch * E) = pack16<T>(o);
+    }
+}
+
+// stage B, round 4: the same arithmetic with a thread bound to ONE 16-byte channel chunk for its whole life (C / E a power of two
+// <= 256: consecutive threads = consecutive chunks of one pixel, the block walks pixels).  The kernel above fetches the chunk's ten
+// 16-byte coefficient vectors (mean / rstd, the two sums, y_std) for EVERY item next to its two data loads; here they are loaded
+// once, and four pixels' operands are requested before the first is used.
+template <typename T>
+__global__ __launch_bounds__(256) void adain_upcat_bwd_apply_rows_kernel(const T* __restrict__ gtmp, const float* __restrict__ sums,
+                                             const T* __restrict__ x, int ldx, const float* __restrict__ stats,
+                                             const float* __restrict__ y_std, T* __restrict__ dx, int lddx,
+                                             float* __restrict__ d_y_std, float* __restrict__ d_y_mean,
+                                             int HW, int C, int x_gate_act) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    constexpr int U = 4;
+    const int cpp = C / E, ppb = 256 / cpp;
+    const int n = blockIdx.y;
+    const int ch = threadIdx.x % cpp, pl = threadIdx.x / cpp;
+    const int sc = n * C + ch * E;
+    const float inv_hw = 1.f / (float)HW, inv_hw1 = 1.f / (float)(HW - 1);
+    float st[2 * E], sm[2 * E], ys[E];
+    ldf<2 * E>(stats + 2 * sc, st);
+    ldf<2 * E>(sums + 2 * sc, sm);
+    ldf<E>(y_std + sc, ys);
+    if (blockIdx.x == 0 && pl == 0) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            d_y_mean[sc + e] = sm[2 * e];
+            d_y_std[sc + e] = sm[2 * e + 1];
+        }
+    }
+    const size_t img = (size_t)n * HW;
+    const int stride = gridDim.x * ppb;
+    for (int pix0 = blockIdx.x * ppb + pl; pix0 < HW; pix0 += U * stride) {
+        uint4 xr[U], gr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pix = min(pix0 + u * stride, HW - 1);
+            xr[u] = *(const uint4*)(x + (img + pix) * ldx + ch * E);
+            gr[u] = *(const uint4*)(gtmp + (img + pix) * C + ch * E);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pix = pix0 + u * stride;
+            if (pix >= HW) break;
+            float xv[E], g[E], o[E];
+            unpack16<T>(xr[u], xv);
+            unpack16<T>(gr[u], g);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float mean = st[2 * e], rstd = st[2 * e + 1], S1 = sm[2 * e], S2 = sm[2 * e + 1];
+                const float xh = (xv[e] - mean) * rstd;
+                o[e] = act_gate(ys[e] * rstd * (g[e] - S1 * inv_hw - xh * S2 * inv_hw1), xv[e], x_gate_act);
+            }
+            *(uint4*)(dx + (img + pix) * lddx + ch * E) = pack16<T>(o);
+        }
     }
 }
 
@@ -1101,10 +1378,35 @@ extern "C" int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int l
     // row round trips dominate (64 -> 32: 108 -> 88 us, 128 -> 64: 160 -> 149 us); two columns (3 loads per column instead of 4) on 256 -> 128
     // (292 vs 310 us)
     const int opt8 = g_wu_opt[WU_OPT_ADAIN_BWD_MARCH];
-    const int ncol = (opt8 == 2 || (opt8 == 1 && W <= 64)) ? 1 : 2;
+    // round 4: bf16 with keep BITS (or no dropout) streams its strips through an LDS ring (adain_upcat_bwd_tile_kernel); option 8 = 5
+    // keeps the marching kernel (A/B).  The re-hash mode (dropout without stored bits) stays on the marching kernel.
+    const bool drop = keep_thr(p_drop) < 0x10000u;
+    const int tile_ct = cdiv(W, upbt::TC);
+    const bool tile = dtype == WU_BF16 && opt8 != 0 && opt8 != 5 && (!drop || mask_bits) && tile_ct <= kMaxSplits &&
+                      (size_t)4 * H * W * lddy * 2 + (size_t)lddy * 2 < 0x7fffffffull && (size_t)H * W * ldx * 2 < 0x7fffffffull &&
+                      ((uintptr_t)mask_bits % 4) == 0;
+    const int ncol = (opt8 == 2 || ((opt8 == 1 || opt8 == 5) && W <= 64)) ? 1 : 2;
     const int col_tiles = cdiv(W, ncol * pp);
     const bool march = g_wu_opt[WU_OPT_ADAIN_BWD_MARCH] && col_tiles <= kMaxSplits;
-    if (march) {
+    if (tile) {
+        // strips: enough workgroups for two per CU with some slack (>= 768), at least 8 low-res rows each (a strip re-reads a one-row
+        // halo and fills / drains its ring once), at most kMaxSplits partial-sum slots per (n, c)
+        int strips = kMaxSplits / tile_ct;
+        const int want = cdiv(768, N * (C / 64) * tile_ct);
+        if (strips > want) strips = want;
+        if (strips > cdiv(H, 8)) strips = cdiv(H, 8);
+        if (strips < 1) strips = 1;
+        const int rows_per_strip = cdiv(H, strips);
+        strips = cdiv(H, rows_per_strip);
+        splits = tile_ct * strips;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)adain_upcat_bwd_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, upbt::SMEM);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(adain_upcat_bwd_tile_kernel, dim3(C / 64, splits, N), dim3(256), upbt::SMEM, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx,
+                           stats, (bf16_t*)gtmp, partials, H, W, C, rows_per_strip, tile_ct, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), mask_bits);
+    } else if (march) {
         int strips = kMaxSplits / col_tiles;
         const int want = cdiv(2048 * (3 - ncol), N * (C / 64) * col_tiles);      // enough workgroups to fill the chip
         if (strips > want) strips = want;
@@ -1125,10 +1427,16 @@ extern "C" int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int l
         DISPATCH_T(dtype, hipLaunchKernelGGL(adain_upcat_bwd_gather_kernel<T>, dim3(C / 64, splits, N), dim3(256), 0, s, (const T*)dy, lddy, (const T*)x, ldx,
                                              stats, (T*)gtmp, partials, H, W, C, sy, sx, keep_thr(p_drop), 1.f / (1.f - p_drop), seed, mask_bits));
     }
+    const int cpp_ = C / (16 / esz);
+    const bool rows = opt8 != 5 && cpp_ <= 256 && (cpp_ & (cpp_ - 1)) == 0;
     DISPATCH_T(dtype, {
         hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(N * C * 2, 256)), dim3(256), 0, s, partials, sums, N * C * 2, splits);
-        hipLaunchKernelGGL(adain_upcat_bwd_apply_kernel<T>, dim3(grid_for((long long)HW * (C / (16 / esz)), 256, 1024), N), dim3(256), 0, s, (const T*)gtmp, sums, (const T*)x, ldx, stats, y_std,
-                           (T*)dx, lddx, d_y_std, d_y_mean, N, HW, C, x_gate_act);
+        if (rows)
+            hipLaunchKernelGGL(adain_upcat_bwd_apply_rows_kernel<T>, dim3(grid_for(cdiv((long long)HW * cpp_, 4), 256, 2048), N), dim3(256), 0, s, (const T*)gtmp, sums,
+                               (const T*)x, ldx, stats, y_std, (T*)dx, lddx, d_y_std, d_y_mean, HW, C, x_gate_act);
+        else
+            hipLaunchKernelGGL(adain_upcat_bwd_apply_kernel<T>, dim3(grid_for((long long)HW * (C / (16 / esz)), 256, 1024), N), dim3(256), 0, s, (const T*)gtmp, sums, (const T*)x, ldx, stats, y_std,
+                               (T*)dx, lddx, d_y_std, d_y_mean, N, HW, C, x_gate_act);
     });
     WU_LAUNCH_CHECK("adain_upcat_bwd");
     return 0;

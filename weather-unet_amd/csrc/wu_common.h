@@ -149,6 +149,11 @@ __device__ __forceinline__ void wu_dma16b(unsigned voff, wu_rsrc_t rsrc, unsigne
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                  :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_addr) : "memory", "m0");
 }
+// the 4-byte form: a 256-byte piece, lane l lands at M0 + 4*l (narrow rows: halo columns, one-byte-per-chunk keep masks)
+__device__ __forceinline__ void wu_dma4b(unsigned voff, wu_rsrc_t rsrc, unsigned soff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_addr) : "memory", "m0");
+}
 
 // ---- XCD-aware block remap ------------------------------------------------------------------------
 // Blocks are dealt round-robin over the 8 XCDs (private 4 MiB L2 each).  Remap so each XCD owns a
