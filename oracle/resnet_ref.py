@@ -114,3 +114,75 @@ def resnet101_forward(p, x, layers=LAYERS, return_stages=False):
     st["feat"] = feat
     out = F.linear(feat, p["fc.weight"], p["fc.bias"])
     return (out, st) if return_stages else out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# bf16 emulation of the HIP estimator (round 4).  NOT torchvision's arithmetic: the same network with every tensor the MI355X
+# kernels park in HBM as bf16 rounded at that point -- BatchNorm folded into the conv weight FIRST (wu/resnet.py: plan()), the
+# folded weight rounded to bf16, the bias kept in fp32, each block's three activations and the downsample branch stored as bf16,
+# and in backward each of the stage's gradient tensors (g_b, g_a, the downsample gradient, the block-input gradient) stored as
+# bf16.  Used to pin the estimator's bf16 BACKWARD block by block (tests/test_gpu_round4.py), as cunet_forward(emulate_bf16=True)
+# does for the generator.
+# ---------------------------------------------------------------------------------------------------------------------------
+class _RoundBF16(torch.autograd.Function):
+    """Value rounded to bf16 in forward (a tensor stored in bf16), the gradient flowing into it rounded in backward."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+def fold_bn(p, conv, bn):
+    """(weight, bias) of conv followed by eval-mode BatchNorm as ONE conv: what ResNet101Estimator.plan() computes."""
+    scale = p[f"{bn}.weight"] / torch.sqrt(p[f"{bn}.running_var"] + BN_EPS)
+    return p[f"{conv}.weight"] * scale.view(-1, 1, 1, 1), p[f"{bn}.bias"] - p[f"{bn}.running_mean"] * scale
+
+
+def bottleneck_bf16(p, prefix, x, stride):
+    """One Bottleneck in the HIP path's bf16 mode; `x` holds bf16-representable values.  Returns (pre, out): the fp32 sum before the
+    final ReLU (the point the stage's upstream gradient enters: the kernels hand a block a gradient already gated by that ReLU) and the
+    stored output."""
+    q = _RoundBF16.apply
+    rw = lambda w: w.to(torch.bfloat16).float()
+    w1, b1 = fold_bn(p, f"{prefix}.conv1", f"{prefix}.bn1")
+    w2, b2 = fold_bn(p, f"{prefix}.conv2", f"{prefix}.bn2")
+    w3, b3 = fold_bn(p, f"{prefix}.conv3", f"{prefix}.bn3")
+    a = q(F.relu(F.conv2d(x, rw(w1), b1)))
+    b = q(F.relu(F.conv2d(a, rw(w2), b2, stride=stride, padding=1)))
+    if f"{prefix}.downsample.0.weight" in p:
+        wd, bd = fold_bn(p, f"{prefix}.downsample.0", f"{prefix}.downsample.1")
+        idn = q(F.conv2d(x, rw(wd), bd, stride=stride))
+    else:
+        idn = x
+    pre = F.conv2d(b, rw(w3), b3) + idn
+    return pre, q(F.relu(pre))
+
+
+def bottleneck_bf16_stage_grad(p, prefix, x, g_out_gated, stride):
+    """The block-input gradient of one Bottleneck in bf16 mode, given the stage input `x` (a ReLU / max-pool output stored in bf16) and
+    the upstream gradient ALREADY gated by the block's final ReLU (what the HIP stage receives): gated by x > 0 and rounded to bf16,
+    as the HIP stage stores it for the previous block."""
+    xin = x.detach().float().requires_grad_(True)
+    pre, out = bottleneck_bf16(p, prefix, xin, stride)
+    pre.backward(g_out_gated.float())
+    g = xin.grad * (x > 0).float()
+    return out.detach(), g.to(torch.bfloat16).float()
+
+
+def resnet101_forward_bf16(p, x, layers=LAYERS):
+    """The whole estimator in the HIP path's bf16 mode (see above): image and folded stem weights rounded to bf16 for the matrix-core
+    stem, every stored activation bf16, pooled features and the classifier in fp32 -> (N, num_classes) raw outputs."""
+    q = _RoundBF16.apply
+    rw = lambda w: w.to(torch.bfloat16).float()
+    ws, bs = fold_bn(p, "conv1", "bn1")
+    h = q(F.relu(F.conv2d(q(x), rw(ws), bs, stride=2, padding=3)))
+    h = F.max_pool2d(h, kernel_size=3, stride=2, padding=1)
+    for li, (planes, blocks, stride) in enumerate(layers, start=1):
+        for b in range(blocks):
+            h = bottleneck_bf16(p, f"layer{li}.{b}", h, stride if b == 0 else 1)[1]
+    feat = torch.flatten(F.adaptive_avg_pool2d(h, 1), 1)
+    return F.linear(feat, p["fc.weight"], p["fc.bias"])

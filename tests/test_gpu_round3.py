@@ -250,6 +250,22 @@ def test_full_size_gan_iteration_is_deterministic(mode, batch):
         moved += int(not torch.equal(b1[k], d_state[k].to(DEV)))
     # the power iteration is ACTIVE in the step (three per iteration); the 1 x 512 head `l` is at its fixed point after one
     assert moved >= 12, f"only {moved} of 20 power-iteration buffers moved"
+    # Round 4 (advisor): the overlapped schedule against the PLAIN order -- one more iteration with every stream overlap, the encoder
+    # sharing and the fence-less ordering events switched off.  A missing wait or a stale operand that repeats run to run (the
+    # cross-stream hazard of DESIGN.md 4 was 10 of 10) passes the two-run comparison above; it cannot pass this one.
+    from wu import train_step as TS, unet_graph as UG
+    saved = (TS.OVERLAP_D_PASSES, TS.OVERLAP_D_WITH_ESTIMATOR, TS.SHARE_ENCODER, UG.LIGHT_EVENTS)
+    try:
+        TS.OVERLAP_D_PASSES = TS.OVERLAP_D_WITH_ESTIMATOR = TS.SHARE_ENCODER = False
+        UG.LIGHT_EVENTS = False
+        l3, g3, b3 = _iteration(st, images, rand_images, d_state)
+    finally:
+        TS.OVERLAP_D_PASSES, TS.OVERLAP_D_WITH_ESTIMATOR, TS.SHARE_ENCODER, UG.LIGHT_EVENTS = saved
+    assert l1 == l3, f"losses differ between the overlapped and the plain order: {l1} vs {l3}"
+    for k in g1:
+        assert torch.equal(g1[k], g3[k]), f"gradient of {k}: overlapped order != plain order"
+    for k in b1:
+        assert torch.equal(b1[k], b3[k]), f"buffer {k}: overlapped order != plain order"
 
 
 def test_full_size_sndisc_production_vs_generic():

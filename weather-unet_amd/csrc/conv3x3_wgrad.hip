@@ -225,26 +225,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradArgs a
 // launch on the side stream, and a workgroup that needs LDS or a 64-register wave cannot be placed on a CU whose 160 KiB / 480 of
 // 512 registers per SIMD lane are held by a persistent conv workgroup -- it then waits for a whole conv KERNEL to retire (measured:
 // 90 us per reducer in the step against 12 us stand-alone).
+// Round 4: WPR waves share a (co, tap) row, each taking a ci range (Cin / WPR channels, whole float4s).  With one wave per row the
+// 256-split rows of the Cin = 64 layers were 64 dependent 16-byte loads per lane from 576 waves: 2.3 MB in flight chip-wide, 1.9 TB/s,
+// 20 us for 37.7 MB.  WPR = 4 there: 16 loads per lane from 2304 waves.  Still no LDS, still <= 32 registers, still one fixed order per
+// (splits, Cin): a lane adds its splits g, g + G, ... in that order and the G lane groups are combined by the same xor tree.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void wgrad_reduce_kernel(
     const float* __restrict__ slab, const float* __restrict__ bslab, float* __restrict__ dw, float* __restrict__ dbias,
-    int splits, int Cout, int Cin, int accumulate) {
+    int splits, int Cout, int Cin, int accumulate, int wpr) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);          // (co, tap) rows, tap fastest: row = co * 9 + t
+    const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // provably wave-uniform: scalar row base
+    const int row = wid / wpr, part = wid - row * wpr;            // (co, tap) rows, tap fastest: row = co * 9 + t
     if (row >= Cout * 9) return;
     const int co = row / 9, t = row - co * 9;
-    const int c4n = Cin >> 2;
-    int TX = 64;                                                  // lanes across ci (float4 each): the largest power of two <= min(Cin/4, 64)
+    const int c4n = (Cin >> 2) / wpr, c4lo = part * c4n;          // this wave's float4 columns [c4lo, c4lo + c4n)
+    int TX = 64;                                                  // lanes across ci (float4 each): the largest power of two <= min(c4n, 64)
     while (TX > c4n) TX >>= 1;
     const int G = 64 / TX;
     const int tx = lane & (TX - 1), g = lane / TX;
+    // wave-uniform row base (scalar registers) + a 32-bit per-lane element offset: the loads take the saddr form, no 64-bit VALU adds
     const float* base = slab + ((size_t)t * Cout + co) * splits * Cin;
     for (int c4b = 0; c4b < c4n; c4b += TX) {                     // wave-uniform trip count (the shuffles below need every lane)
         const int c4 = c4b + tx;
         const bool valid = c4 < c4n;
-        const float* p = base + (valid ? c4 : 0) * 4;
+        unsigned off = (unsigned)(g * Cin + (c4lo + (valid ? c4 : 0)) * 4);
+        const unsigned step = (unsigned)(G * Cin);
         float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);           // one chain: registers are what places this kernel beside a conv workgroup
-        for (int k = g; k < splits; k += G) {
-            const float4 v0 = *(const float4*)(p + (size_t)k * Cin);
+        int k = g;
+        for (; k + G < splits; k += 2 * G, off += 2 * step) {     // two loads in flight per lane
+            const float4 v0 = *(const float4*)(base + off);
+            const float4 v1 = *(const float4*)(base + off + step);
+            sacc.x += v0.x; sacc.y += v0.y; sacc.z += v0.z; sacc.w += v0.w;
+            sacc.x += v1.x; sacc.y += v1.y; sacc.z += v1.z; sacc.w += v1.w;
+        }
+        if (k < splits) {
+            const float4 v0 = *(const float4*)(base + off);
             sacc.x += v0.x; sacc.y += v0.y; sacc.z += v0.z; sacc.w += v0.w;
         }
         for (int m = TX; m < 64; m <<= 1) {                       // combine the G groups (lanes tx + j * TX): fixed xor tree
@@ -252,12 +266,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void wgra
             sacc.z += __shfl_xor(sacc.z, m); sacc.w += __shfl_xor(sacc.w, m);
         }
         if (g == 0 && valid) {
-            float* o = dw + ((size_t)co * Cin + c4 * 4) * 9 + t;
+            float* o = dw + ((size_t)co * Cin + (c4lo + c4) * 4) * 9 + t;
             if (accumulate) { o[0] += sacc.x; o[9] += sacc.y; o[18] += sacc.z; o[27] += sacc.w; }
             else { o[0] = sacc.x; o[9] = sacc.y; o[18] = sacc.z; o[27] = sacc.w; }
         }
     }
-    if (dbias && t == 0) {      // bias partials [split][Cout]: lanes stride the splits, xor-shuffle tree
+    if (dbias && t == 0 && part == 0) {      // bias partials [split][Cout]: lanes stride the splits, xor-shuffle tree
         float b = 0.f;
         for (int k = lane; k < splits; k += 64) b += bslab[(size_t)k * Cout + co];
         for (int m = 1; m < 64; m <<= 1) b += __shfl_xor(b, m);
@@ -266,7 +280,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void wgra
 }
 
 void launch_wgrad_reduce(const float* slab, const float* bslab, float* dw, float* dbias, int splits, int Cout, int Cin, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(Cout * 9, 4)), dim3(256), 0, s, slab, bslab, dw, dbias, splits, Cout, Cin, accumulate);
+    // waves per row: ~16 loads per lane (splits x Cin/4 float4 over 64 lanes), a power of two that divides Cin / 4 into whole float4 ranges
+    int wpr = 1;
+    while (wpr < 8 && (long long)splits * (Cin >> 2) > 64LL * 16 * wpr && ((Cin >> 2) % (2 * wpr)) == 0) wpr <<= 1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(Cout * 9 * wpr, 4)), dim3(256), 0, s, slab, bslab, dw, dbias, splits, Cout, Cin, accumulate, wpr);
 }
 
 struct WPlan { int P, twl, tiles_x, tiles_y, ntiles, splits, halo_w, halo_h; size_t lds, ws; };

@@ -1389,10 +1389,11 @@ extern "C" int wu_adain_upcat_bwd(const void* dy, int lddy, const void* x, int l
     const int col_tiles = cdiv(W, ncol * pp);
     const bool march = g_wu_opt[WU_OPT_ADAIN_BWD_MARCH] && col_tiles <= kMaxSplits;
     if (tile) {
-        // strips: enough workgroups for two per CU with some slack (>= 768), at least 8 low-res rows each (a strip re-reads a one-row
-        // halo and fills / drains its ring once), at most kMaxSplits partial-sum slots per (n, c)
+        // strips: two workgroups fit a CU, so the grid should be a multiple of 2 x CUs -- 768 workgroups ran as one full wave of 512 and
+        // a half-empty one (measured: no faster than the marching kernel); 1024 at B = 32 on all three levels.  At least 8 low-res rows
+        // per strip (a strip re-reads a one-row halo and fills / drains its ring once), at most kMaxSplits partial-sum slots per (n, c)
         int strips = kMaxSplits / tile_ct;
-        const int want = cdiv(768, N * (C / 64) * tile_ct);
+        const int want = cdiv(4 * wu_num_cus(), N * (C / 64) * tile_ct);
         if (strips > want) strips = want;
         if (strips > cdiv(H, 8)) strips = cdiv(H, 8);
         if (strips < 1) strips = 1;

@@ -38,11 +38,13 @@ extern "C" int wu_stream_destroy(void* stream) {
 // Ordering events between two streams of ONE device: no timing, no system-scope fence.  torch's wait_stream() records a default-flag
 // event: every record is then a system-scope release (write-back towards the host) on the recording stream -- 14 of them per training
 // step on the critical path of the fused backward (one per weight-gradient hand-off).  Kernels on another stream of the same device
-// need device-scope visibility only, which hipEventDisableSystemFence keeps.
+// need device-scope visibility only: a timing-less event with a device-scope release.
 extern "C" int wu_event_create(void** event_out) {
     WU_REQUIRE(event_out, "event_create: bad args");
     hipEvent_t e = nullptr;
-    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
+    // hipEventReleaseToDevice: the DOCUMENTED device-scope release at the record (round 4, advisor).  Round 3 used
+    // hipEventDisableSystemFence, which HIP documents for timing events only -- what it leaves of the release is an implementation detail.
+    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice);
     if (rc != hipSuccess) WU_FAIL((int)rc, "hipEventCreateWithFlags: %s", hipGetErrorString(rc));
     *event_out = (void*)e;
     return 0;

@@ -81,11 +81,6 @@ class SNDisc(nn.Module):
         train = layers[0].training
         w_eff = WF.spectral_normalize_multi([m.weight_orig for m in layers], [m.weight_u for m in layers], [m.weight_v for m in layers],
                                             train, layers[0].eps)
-        ev = _SN_DONE.get(self)
-        if ev is None:
-            ev = _SN_DONE[self] = torch.cuda.Event()
-        ev.record()                                          # the power-iteration buffers are final for this forward (wu/train_step.py)
-        self.sn_batched_last = True
         for m, w in zip(layers, w_eff):
             if train:
                 m._sn_generation += 1
@@ -96,6 +91,14 @@ class SNDisc(nn.Module):
             for (m, w), (wf, wd) in zip(todo, K.pack_conv3x3_multi([w for _, w in todo], code)):
                 m._packed.w_fwd, m._packed.w_dgrad = wf, wd
                 m._packed.key = m._packed.make_key(w, code, m.weight_ident())
+        # Recorded AFTER the pack launch (round 4, advisor): in eval mode the cache key does not change between the two passes of
+        # update_discriminator, so a pass on the other stream finds the operands "fresh" and waits for this event only -- it must
+        # cover the kernel that writes them, not just the power iteration (wu/train_step.py).
+        ev = _SN_DONE.get(self)
+        if ev is None:
+            ev = _SN_DONE[self] = torch.cuda.Event()
+        ev.record()                                          # buffers AND packed operands are final for this forward
+        self.sn_batched_last = True
         return layers
 
     def forward(self, x, c=None):

@@ -88,6 +88,7 @@ SIGNATURES = {
 }
 
 _lib = None
+LOADED_PATH = None       # the file load() actually opened (bench.py reports it when it is not the in-tree library)
 
 
 def load():
@@ -107,7 +108,14 @@ def load():
         ab = os.environ.get("WU_AB_LIB")
         if not ab:
             _check_not_stale()
-        lib = ctypes.CDLL(ab or LIB_PATH)
+        else:
+            # never silently: a leftover variable would run training on a stale baseline build (advisor, round 3)
+            import sys
+            print(f"[wu] WARNING: WU_AB_LIB is set -- running on {ab} instead of {LIB_PATH}; no staleness check, entry points "
+                  "that build lacks stay unbound.  Benchmark A/B harness only (scratch/ab_lib.py).", file=sys.stderr, flush=True)
+        global LOADED_PATH
+        LOADED_PATH = ab or LIB_PATH
+        lib = ctypes.CDLL(LOADED_PATH)
         for name, (res, args) in SIGNATURES.items():
             if ab and not hasattr(lib, name):
                 continue

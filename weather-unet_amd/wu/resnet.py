@@ -26,6 +26,9 @@ from . import kernels as K
 from .layout import dtype_code, empty_nhwc, nhwc_ld, precision_code, require_cuda, stream_ptr, torch_dtype
 
 RELU, NONE = K.ACT_RELU, K.ACT_NONE
+# tracing: set to a list and the next backward appends, per Bottleneck (last block first), its stage input, stored output, the gated
+# upstream gradient it received and the block-input gradient it produced; None = off (no cost, no references kept)
+CAPTURE = None
 LAYERS = ((64, 3, 1), (128, 4, 2), (256, 23, 2), (512, 3, 2))     # torchvision resnet101: (planes, blocks, stride)
 EXPANSION = 4
 BN_EPS = 1e-5
@@ -254,8 +257,9 @@ class ResNetFn(Function):
         gf = (gfeat.float() * (1.0 / (hh * ww))).contiguous()
         _lib.call("wu_sumpool_bwd", gf.data_ptr(), g.data_ptr(), nhwc_ld(g), n, hh, ww, c, code, stream_ptr())
         g = K.act_gate(g, last, RELU, out=g)                        # gradient wrt the last block's pre-ReLU sum
-        for blk, (xin, a, b, out) in zip(reversed(plan["blocks"]), reversed(saved)):
+        for bi, (blk, (xin, a, b, out)) in enumerate(zip(reversed(plan["blocks"]), reversed(saved))):
             s, planes = blk["stride"], blk["planes"]
+            g_out = g
             # g: gradient of this block's output, already gated by its final ReLU
             gb = conv1x1(g, blk["c3"]["wt"], None, new(planes, b.shape[2], b.shape[3]), NONE, egate=b, egate_act=RELU)
             ga = new(planes, a.shape[2], a.shape[3])
@@ -271,6 +275,8 @@ class ResNetFn(Function):
             # input is a ReLU output; for the first block it is max-pool(ReLU(stem)): x > 0 there implies the routed stem element > 0)
             g = conv1x1(ga, blk["c1"]["wt"], None, new(xin.shape[1], xin.shape[2], xin.shape[3]), NONE, residual=skip,
                         egate=xin, egate_act=RELU)
+            if CAPTURE is not None:      # tracing hook (tests: block-by-block gradient checks with the upstream gradient held fixed)
+                CAPTURE.append({"block": len(saved) - 1 - bi, "stride": s, "xin": xin, "out": out, "g_out": g_out, "g_in": g})
         gstem = maxpool3s2_bwd(g, amax, stem, new(64, stem.shape[2], stem.shape[3]), gate_act=RELU)
         dx = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
         stem7x7_dgrad(gstem, plan["stem_w"], dx, code)

