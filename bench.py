@@ -229,12 +229,19 @@ def main():
             families_timed = [max(pre_stats, key=lambda f: pre_stats[f]["ms"])]
     if do_roof:
         _lib.prof_begin(families_timed, (64 if gan is None else 1024) * a.steps + 64)
+    # one timing-only event per step boundary (recorded on the main stream, no synchronisation): the per-step MEDIAN reported next to
+    # the mean -- a single DVFS excursion moves the mean of a 0.1-0.2 s timed region by a few per cent, not the median
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         last = step()
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    step_median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if use_ddp:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -250,6 +257,18 @@ def main():
                     stats[f] = {k: v * a.steps for k, v in pre_stats[f].items()}
         measured_flops = sum(st["flops"] for st in stats.values())     # algorithmic conv FLOPs of the launches in the timed region
         _lib.prof_end()
+        graph_note = None
+        if graphed is not None:
+            # a replayed hipGraph contains no event brackets (they cannot be captured per launch): the same forward is run EAGERLY three
+            # more times after the timed region with every conv launch bracketed, and the roofline block is computed from those
+            _lib.prof_begin(families, 64 * 3 + 64)
+            with torch.no_grad():
+                for _ in range(3):
+                    net(x, c)
+            torch.cuda.synchronize()
+            stats = {f: _lib.prof_query(f) for f in families}
+            _lib.prof_end()
+            graph_note = "3 eager forwards after the timed graph replays, every launch of the listed families bracketed (a replayed graph has no per-launch events)"
         # In the training step the weight-gradient kernels run on a second HIP stream beside the data-gradient chain (faster
         # step), so the per-launch durations above include the time a kernel shares the chip.  A short extra pass with that
         # overlap switched off gives the kernels' stand-alone rate, reported next to the in-step figure.
@@ -293,8 +312,9 @@ def main():
                     "algorithmic_bytes_per_launch": round(s["bytes"] / s["launches"]),
                     "avg_launch_ms": round(s["ms"] / s["launches"], 4),
                     "algorithmic_gflop_per_launch": round(s["flops"] / s["launches"] / 1e9, 3),
-                    "share_of_step": round(s["ms"] / (dt * 1e3), 3),
-                    "instrumented": ("dominant family bracketed in the timed region; other_kernels from one untimed fully instrumented iteration"
+                    "share_of_step": (round(s["ms"] / 3 / (dt / a.steps * 1e3), 3) if graph_note is not None else round(s["ms"] / (dt * 1e3), 3)),
+                    "instrumented": (graph_note if graph_note is not None else
+                                     "dominant family bracketed in the timed region; other_kernels from one untimed fully instrumented iteration"
                                      if pre_stats is not None else "every launch of the listed families bracketed in the timed region"),
                     "single_stream": (None if iso is None or not iso[dom]["launches"] else
                                       {"achieved": round(iso[dom]["flops"] / (iso[dom]["ms"] * 1e-3) / 1e12, 2),
@@ -318,7 +338,8 @@ def main():
             "metric": ("images/sec GAN iteration (D update + G update)" if gan is not None else
                        "images/sec 256x256 cUNet fwd+bwd" if not a.fwd_only else "images/sec cUNet forward (eval)"),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "ms_per_step_median": round(step_median, 3),
+            "ms_per_step_min_max": [round(per_step[0], 3), round(per_step[-1], 3)], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": (f"{'t_' + a.workload[4:] + '_train GAN loop (cUNet + SNDisc + estimator)' if gan is not None else 'cUNet'} "
                                     f"{a.size}x{a.size} {a.precision} B={a.batch}/GPU, "
@@ -337,6 +358,8 @@ def main():
         }
         if roof is not None:
             res["roofline"] = roof
+        if _lib.LOADED_PATH and os.path.realpath(_lib.LOADED_PATH) != os.path.realpath(_lib.LIB_PATH):
+            res["library"] = _lib.LOADED_PATH              # WU_AB_LIB: an A/B run on another build, never a headline number
         if world == 1 and not a.no_cpu_baseline and not a.fwd_only and gan is None:
             res["cpu_baseline"] = cpu_baseline(a.size)
         print(json.dumps(res), flush=True)

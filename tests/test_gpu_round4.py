@@ -130,3 +130,53 @@ def test_estimator_bf16_backward_block_by_block():
     # the HIP path must be no further from the emulation than the emulation is from fp32 (plus slack): what separates it from fp32 is
     # the precision mode, not the kernels
     assert c_emu >= min(0.999, c_emu_f32 - 0.002), (c_emu, c_emu_f32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# SNDisc's conv trunk as one autograd node (wu/disc_graph.py; reference disc.py:27-32)
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("case", ["d_update", "g_update_frozen", "feature_losses"])
+def test_sndisc_fused_trunk_is_bitwise_the_per_layer_path(precision, case):
+    """The single-node trunk launches the same kernels as the per-layer autograd path and applies the LeakyReLU gates in the
+    data-gradient epilogues (same roundings): outputs, the four feature maps, all 20 parameter gradients, the input gradient and the
+    power-iteration buffers are BIT-IDENTICAL -- for the discriminator update (parameter gradients), the generator update (D frozen:
+    data gradient only, no weight-gradient kernels) and a loss that also reads the returned feature maps c1..c4."""
+    import disc
+    dev, nc = _dev(), 5
+    x = _rand((3, 3, 64, 96), 11).to(dev)
+    c = torch.softmax(_rand((3, nc), 12), dim=1).to(dev)
+    torch.manual_seed(4)
+    ref = disc.SNDisc(nc, precision=precision).to(dev).train()
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    res = {}
+    saved = disc.FUSED_TRUNK
+    try:
+        for fused in (False, True):
+            disc.FUSED_TRUNK = fused
+            D = disc.SNDisc(nc, precision=precision).to(dev).train()
+            D.load_state_dict(state)
+            if case == "g_update_frozen":
+                for q in D.parameters():
+                    q.requires_grad_(False)
+            xd = x.clone().requires_grad_(True)
+            outs = D(xd, c)
+            loss = torch.mean(torch.relu(1.0 - outs[0])) + torch.mean(torch.relu(1.0 + outs[0]))
+            if case == "feature_losses":
+                loss = loss + sum(o.float().abs().mean() for o in outs[1:]) * 0.1
+            loss.backward()
+            torch.cuda.synchronize()
+            res[fused] = ([o.detach().float().clone() for o in outs], {k: q.grad.clone() for k, q in D.named_parameters() if q.grad is not None},
+                          xd.grad.clone(), {k: v.clone() for k, v in D.state_dict().items() if k.endswith(("weight_u", "weight_v"))})
+    finally:
+        disc.FUSED_TRUNK = saved
+    (o0, g0, dx0, b0), (o1, g1, dx1, b1) = res[False], res[True]
+    for i, (a, b) in enumerate(zip(o0, o1)):
+        assert torch.equal(a, b), f"output {i} differs"
+    assert set(g0) == set(g1) and len(g0) == (0 if case == "g_update_frozen" else 20)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), f"gradient of {k} differs (max {(g0[k] - g1[k]).abs().max().item():.3e})"
+    assert torch.isfinite(dx0).all() and dx0.abs().max().item() > 0
+    assert torch.equal(dx0, dx1), f"input gradient differs (max {(dx0 - dx1).abs().max().item():.3e})"
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k

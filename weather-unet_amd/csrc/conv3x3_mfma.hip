@@ -64,7 +64,7 @@ template <> struct Mma<float> {
 __device__ __forceinline__ int swz_off(int row, int slot) { return row * kChunkBytes + ((slot ^ ((row >> 2) & 3)) << 4); }
 
 template <typename T, int STRIDE, bool MASKED, int NHALO>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv3x3_mfma_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int kChunkElems = kChunkBytes / (int)sizeof(T);
     char* halo_lds = smem;
@@ -88,20 +88,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     const T* xmask = MASKED ? (const T*)a.mask + (size_t)n * a.H * a.W * a.ldmask : nullptr;
 
     // ---- per-thread staging descriptors: item = (halo pixel, 16-B slot) ----
-    int hoff[NHALO];   // element offset of the pixel inside image n (-1: zero fill / unused)
+    int hoff[NHALO];   // element offset of the pixel inside image n (-1: zero fill; -2: no such item)
     int moff[MASKED ? NHALO : 1];
-    int hdst[NHALO];   // LDS byte offset
 #pragma unroll
     for (int k = 0; k < NHALO; ++k) {
         const int item = tid + 256 * k;
         const int p = item >> 2, slot = item & 3;
-        hoff[k] = -1;
-        hdst[k] = -1;
+        hoff[k] = -2;
         if (MASKED) moff[k] = -1;
         if (p < a.halo_pix) {
             const int hy = p / a.halo_w, hx = p - hy * a.halo_w;
             const int ih = ih0 + hy, iw = iw0 + hx;
-            hdst[k] = swz_off(p, slot);
+            hoff[k] = -1;
             if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
                 hoff[k] = (ih * a.W + iw) * a.ldx + slot * (16 / (int)sizeof(T));
                 if (MASKED) moff[k] = (ih * a.W + iw) * a.ldmask + slot * (16 / (int)sizeof(T));
@@ -157,10 +155,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     auto store_chunk = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NHALO; ++k) {
-            if (hdst[k] >= 0) {
+            if (hoff[k] != -2) {                 // the LDS slot follows from the item index (kept in no register)
                 uint4 v = hreg[k];
                 if (MASKED) v = gate16<T>(v, mreg[k], a.mask_act);
-                *(uint4*)(halo_lds + hdst[k]) = v;
+                const int item = tid + 256 * k;
+                *(uint4*)(halo_lds + swz_off(item >> 2, item & 3)) = v;
             }
         }
 #define WU_STOREW(t) *(uint4*)(w_lds + (t) * (kBN * kChunkBytes) + wdst) = wr##t;
@@ -168,51 +167,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
 #undef WU_STOREW
     };
 
-    // stride-2 tiles have a 4x larger halo: staged global -> LDS directly (no register prefetch)
-    auto stage_direct = [&](int c0) __attribute__((always_inline)) {
-        // batches of 4 UNCONDITIONAL loads from clamped coordinates, zeroed afterwards (a conditional load in a rolled loop is
-        // one full memory round trip per item)
-        const int nitems = a.halo_pix * 4;
-        for (int item0 = tid; item0 < nitems; item0 += 1024) {
-            uint4 v[4];
-            bool okv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int item = min(item0 + 256 * u, nitems - 1);
-                const int p = item >> 2, slot = item & 3;
-                const int hy = p / a.halo_w, hx = p - hy * a.halo_w;
-                const int ih = ih0 + hy, iw = iw0 + hx;
-                okv[u] = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-                v[u] = *(const uint4*)(xin + (size_t)(min(max(ih, 0), a.H - 1) * a.W + min(max(iw, 0), a.W - 1)) * a.ldx + slot * (16 / (int)sizeof(T)) + c0);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int item = item0 + 256 * u;
-                if (item < nitems) {
-                    // zero padding as a lane mask: a 128-bit select between a register and a constant is lowered through scratch memory
-                    const uint32_t m = okv[u] ? 0xffffffffu : 0u;
-                    *(uint4*)(halo_lds + swz_off(item >> 2, item & 3)) = make_uint4(v[u].x & m, v[u].y & m, v[u].z & m, v[u].w & m);
-                }
-            }
-        }
-#define WU_COPYW(t) *(uint4*)(w_lds + (t) * (kBN * kChunkBytes) + wdst) = *(const uint4*)(wsrc + (t) * wtap_stride + c0);
-        WU_REP9(WU_COPYW)
-#undef WU_COPYW
-    };
-
     const int nchunks = a.Cin / kChunkElems;
-    if constexpr (STRIDE == 1) {
-        load_chunk(0);
-        store_chunk();
-        __syncthreads();
-    }
+    // Both strides: chunk k+1 travels global -> registers under the MFMAs of chunk k, then registers -> LDS between two barriers.
+    // (Round 4: the stride-2 tiles -- a 4x larger halo, 17-19 items per thread -- used to be staged global -> LDS synchronously in
+    //  front of every chunk's MFMAs, with one workgroup per CU: nothing overlapped, 146-168 TFLOP/s.)
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
-        if constexpr (STRIDE == 1) {
-            if (c + 1 < nchunks) load_chunk((c + 1) * kChunkElems);
-        } else {
-            stage_direct(c * kChunkElems);
-            __syncthreads();
-        }
+        if (c + 1 < nchunks) load_chunk((c + 1) * kChunkElems);
 #pragma unroll 1
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -236,11 +199,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
             }
         }
         __syncthreads();
-        if constexpr (STRIDE == 1) {
-            if (c + 1 < nchunks) {
-                store_chunk();
-                __syncthreads();
-            }
+        if (c + 1 < nchunks) {
+            store_chunk();
+            __syncthreads();
         }
     }
 
@@ -290,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
 
 template <typename T, int STRIDE, bool MASKED>
 int launch_conv(const ConvArgs& a, size_t lds_bytes, int grid, hipStream_t s) {
-    constexpr int NH = STRIDE == 1 ? 7 : 1;   // stride 2 stages without per-thread descriptors
+    constexpr int NH = STRIDE == 1 ? 7 : 19;  // staging items per thread: halo pixels x 4 slots / 256 (stride 2: up to 129 x 9 halo pixels)
     auto kern = conv3x3_mfma_kernel<T, STRIDE, MASKED, NH>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
@@ -333,7 +294,7 @@ extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, cons
     a.tiles_x = cdiv(a.Wo, TW); a.tiles_y = cdiv(a.Ho, TH); a.cout_tiles = Cout / kBN;
     a.halo_w = (TW - 1) * stride + 3; a.halo_h = (TH - 1) * stride + 3;
     a.halo_pix = a.halo_w * a.halo_h;
-    if (stride == 1) WU_REQUIRE(a.halo_pix <= 7 * 256 / 4, "conv3x3_fwd: halo %d exceeds staging capacity", a.halo_pix);
+    WU_REQUIRE(a.halo_pix <= (stride == 1 ? 7 : 19) * 256 / 4, "conv3x3_fwd: halo %d exceeds staging capacity", a.halo_pix);
     size_t lds = (size_t)a.halo_pix * kChunkBytes + 9 * kBN * kChunkBytes;
     const size_t epi = (size_t)kTilePix * (kBN * esz + 16);
     if (epi > lds) lds = epi;

@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from nets import SNLinear, sn_double_conv
 from utils import ConditionalNorm  # noqa: F401  (imported by the reference, disc.py:5)
+from wu import disc_graph as DG
 from wu import functional as WF
 from wu import kernels as K
 from wu.layout import precision_code, require_cuda
@@ -23,6 +24,10 @@ from wu.layout import precision_code, require_cuda
 
 # one batched spectral normalisation per forward (default) or one per layer (A/B switch, WU_SN_BATCHED=0)
 BATCHED_SPECTRAL_NORM = os.environ.get("WU_SN_BATCHED", "1") == "1"
+
+
+# the conv trunk as one autograd node (default) or one node per layer (A/B switch, WU_DISC_FUSED=0)
+FUSED_TRUNK = os.environ.get("WU_DISC_FUSED", "1") == "1"
 
 
 _SN_DONE = weakref.WeakKeyDictionary()
@@ -111,11 +116,18 @@ class SNDisc(nn.Module):
                 m._w_eff_next = None
 
     def _forward(self, x, c):
-        c1 = self.conv1(x)                                   # :28
-        c2 = self.conv2(c1)                                  # :29
-        c3 = self.conv3(c2)                                  # :30
-        c4 = self.conv4(c3)                                  # :31
-        x = WF.sumpool(c4)                                   # :32 global pool (sum over H, W), fp32 (N,512)
+        if FUSED_TRUNK and x.is_cuda:
+            # :28-32 as ONE autograd node (wu/disc_graph.py): same kernels, one static schedule, LeakyReLU gates in the data-gradient
+            # epilogues; bit-identical to the per-layer path below
+            convs = [m for i in range(1, 5) for m in getattr(self, 'conv{}'.format(i))[:2]]
+            ws = [m.effective_weight() for m in convs]       # handed in by the batched normalisation, or normalised here layer by layer
+            x, c1, c2, c3, c4 = DG.trunk(x, ws, [m.bias for m in convs], [(m._packed, m.weight_ident()) for m in convs[2:]], self.precision)
+        else:
+            c1 = self.conv1(x)                               # :28
+            c2 = self.conv2(c1)                              # :29
+            c3 = self.conv3(c2)                              # :30
+            c4 = self.conv4(c3)                              # :31
+            x = WF.sumpool(c4)                               # :32 global pool (sum over H, W), fp32 (N,512)
         out = self.l(x)                                      # :33
         e_c = self.embed(c.to(device=x.device, dtype=torch.float32))   # :34 (c=None raises here, as in the reference)
         if c is not None:
