@@ -42,8 +42,22 @@ def main():
             ts.append(e0.elapsed_time(e1) * 1e3 / inner)
         return statistics.median(ts)
 
-    def act(c, s):
-        return (torch.rand((B, s, s, c), device=dev) * 2 - 1).to(bf).permute(0, 3, 1, 2)
+    def act(c, s, relu=False):
+        """A synthetic NHWC activation / gradient: U(-1, 1), or -- for the convs whose input IS a ReLU output in the step (every conv
+        except the decoders' first, whose upsampled half is an AdaIN / dropout output) -- ReLU(N(0, 1)): half zeros.  Round 4
+        (scratch/down12_probe.py, profiles/r04_down12_probe.txt): the same 64 -> 64 @256 forward runs 153-164 us on the latter and
+        162-185 us on the former (the matrix pipe's power follows the operand toggling), and 206 us as the FIRST kernel timed in a
+        process -- which is how r03's table read 202 us for down1.2 where the in-step PMC pass read 154 us."""
+        t = torch.relu(torch.randn((B, s, s, c), device=dev)) if relu else torch.rand((B, s, s, c), device=dev) * 2 - 1
+        return t.to(bf).permute(0, 3, 1, 2)
+
+    # warm-up: ~0.3 s of matrix work before the first timed row (the first timings of a process run 10-25 % slow)
+    _wx, _wy = act(128, 128), empty_nhwc(B, 128, 128, 128, bf, dev)
+    _wf, _ = K.pack_conv3x3((torch.rand((128, 128, 3, 3), device=dev) * 2 - 1) * 0.05, 1)
+    for _ in range(1500):
+        K.conv3x3(_wx, _wf, None, _wy, 1, 1)
+    torch.cuda.synchronize()
+    del _wx, _wy, _wf
 
     rows_conv, rows_glue = [], []
     # the variants the fused graph launches (wu/unet_graph.py): a block's FIRST conv writes the gate bits of its output and its data
@@ -54,7 +68,7 @@ def main():
               ("up2.0", 384, 128, S // 2, "bits"), ("up2.2", 128, 128, S // 2, "plain"), ("up1.0", 192, 64, S, "bits"), ("up1.2", 64, 64, S, "plain")]
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     for name, ci, co, s, kind in layers:
-        x, gy = act(ci, s), act(co, s)
+        x, gy = act(ci, s, relu=kind != "bits" or name.startswith("down")), act(co, s)
         w = (torch.rand((co, ci, 3, 3), device=dev) * 2 - 1) * 0.05
         wf, wd = K.pack_conv3x3(w, 1)
         bias = torch.zeros(co, device=dev)
@@ -95,8 +109,8 @@ def main():
         g(f"adain_stats C={c} @{h}", run(lambda: K.adain_stats(x, 1e-5)), lo)
         g(f"adain_upcat_fwd C={c} {h}->{2 * h} (p=0.3, mask bits)", run(lambda: K.adain_upcat(x, st, ys, ym, cat, 0.3, 123, True)), lo + hi + hi // 16)
         mb = K.adain_upcat(x, st, ys, ym, cat, 0.3, 123, True)
-        g(f"adain_upcat_bwd C={c} {2 * h}->{h} (gather + apply, gated)", run(lambda: K.adain_upcat_bwd(gc, x, st, ys, dx, 0.3, 123, mb, 1)),
-          hi + hi // 16 + lo + lo)          # dy + mask + x read once, dx written (the parked g' round trip is NOT algorithmic)
+        g(f"adain_upcat_bwd C={c} {2 * h}->{h} (stage A + fold + apply, gated)", run(lambda: K.adain_upcat_bwd(gc, x, st, ys, dx, 0.3, 123, mb, 1)),
+          hi + hi // 16 + lo + lo)          # dy + mask + x read once, dx written (the parked g' round trip and the second read of x are NOT algorithmic)
         del x, cat, gc, dx
     for (c, h) in [(64, S), (128, S // 2), (256, S // 4)]:
         x, gs = act(c, h), act(c, h)

@@ -180,3 +180,50 @@ def test_sndisc_fused_trunk_is_bitwise_the_per_layer_path(precision, case):
     assert torch.equal(dx0, dx1), f"input gradient differs (max {(dx0 - dx1).abs().max().item():.3e})"
     for k in b0:
         assert torch.equal(b0[k], b1[k]), k
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# stride-2 data gradient as four parity-class convs (csrc/conv3x3_mfma.hip SPARSE instances; nets.py:30-31 backward)
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("shape", [(2, 64, 128, 16, 32), (1, 128, 64, 11, 13), (3, 64, 64, 5, 7), (1, 256, 128, 34, 40), (2, 64, 64, 2, 2)])
+@pytest.mark.parametrize("gated", [False, True])
+def test_stride2_dgrad_parity_classes(precision, shape, gated):
+    """dX of y = conv3x3(x, w, stride 2, pad 1) from a given dY: the four sparse-tap convs (one per parity class of the input site) against
+    float64 autograd on the same (rounded) operands and against the zero-stuffing path they replace -- odd heights / widths (a last row /
+    column without a partner), one-tile and many-tile images, with and without the LeakyReLU gate of the consumer in the epilogue."""
+    import torch.nn.functional as F
+    from wu import _lib, kernels as K
+    from wu.layout import as_nhwc, empty_nhwc, precision_code
+    n, cin, cout, h, w = shape
+    dev, code = _dev(), precision_code(precision)
+    dt = torch.float32 if precision == "fp32" else torch.bfloat16
+    rnd = lambda t: t.to(dt).float()
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    wt = rnd(_rand((cout, cin, 3, 3), 21, -0.1, 0.1))
+    gy = rnd(_rand((n, cout, ho, wo), 22))
+    xg = rnd(_rand((n, cin, h, w), 23))                      # the tensor whose LeakyReLU gates dX (the previous block's output)
+    x64 = torch.zeros((n, cin, h, w), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x64, wt.double(), stride=2, padding=1).backward(gy.double())
+    want = x64.grad.float()
+    if gated:
+        want = want * torch.where(xg > 0, torch.ones_like(xg), torch.full_like(xg, 0.2))
+    _, wd = K.pack_conv3x3(wt.to(dev), code)
+    gyd = as_nhwc(gy.to(dev), code)
+    eg = as_nhwc(xg.to(dev), code) if gated else None
+    res = {}
+    try:
+        for opt in (1, 0):
+            _lib.call("wu_set_option", 14, opt)
+            dx = empty_nhwc(n, cin, h, w, dt, dev)
+            dx.fill_(float("nan"))
+            K.conv3x3_s2_dgrad(gyd, wd, dx, egate=eg, egate_act=K.ACT_LEAKY if gated else K.ACT_NONE)
+            torch.cuda.synchronize()
+            res[opt] = dx.float().cpu()
+    finally:
+        _lib.call("wu_set_option", 14, 1)
+    tol = (2e-4 if precision == "fp32" else 1.2e-2) * max(1.0, want.abs().max().item())
+    for opt in (1, 0):
+        assert not torch.isnan(res[opt]).any(), f"path {opt} left sites unwritten"
+        err = (res[opt] - want).abs().max().item()
+        assert err <= tol, f"path {opt}: {err} vs tolerance {tol}"

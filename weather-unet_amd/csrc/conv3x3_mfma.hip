@@ -42,6 +42,12 @@ struct ConvArgs {
     int tw_log2;      // tile width  = 1 << tw_log2  (output pixels)
     int tiles_x, tiles_y, cout_tiles;
     int halo_w, halo_h, halo_pix;
+    // SPARSE instances (round 4: one parity class of the stride-2 data gradient): a LIST of taps instead of the full 3 x 3 -- tap t reads
+    // the halo at (tap_dy, tap_dx) (0..2, as kh / kw) and multiplies by slab tap_w[t] of the 9-slab weight pack -- and output pixel
+    // (oh, ow) of the Ho x Wo grid lands at (oh * osy + ooy, ow * osx + oox) of an OH x OW image (skipped when outside it)
+    // Up to four such (tap list, output offset) CLASSES share one launch: the class is the slowest digit of the block index.
+    int nclasses, cls_ntaps[4], cls_tap_dy[4][4], cls_tap_dx[4][4], cls_tap_w[4][4], cls_ooy[4], cls_oox[4];
+    int osy, osx, OH, OW;
 };
 
 template <typename T> struct Mma;
@@ -63,8 +69,9 @@ template <> struct Mma<float> {
 
 __device__ __forceinline__ int swz_off(int row, int slot) { return row * kChunkBytes + ((slot ^ ((row >> 2) & 3)) << 4); }
 
-template <typename T, int STRIDE, bool MASKED, int NHALO>
+template <typename T, int STRIDE, bool MASKED, int NHALO, bool SPARSE = false>
 __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv3x3_mfma_kernel(const ConvArgs a) {
+    static_assert(!SPARSE || STRIDE == 1, "tap lists are a stride-1 form");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int kChunkElems = kChunkBytes / (int)sizeof(T);
     char* halo_lds = smem;
@@ -75,10 +82,15 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv3x3_mfma_kernel(
 
     // ---- which tile ----
     int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // (SPARSE) which tap list / output offset this workgroup computes: the FASTEST digit -- the classes of one tile read the same input
+    // tile (L2 hits) and every XCD's contiguous range of logical ids holds the same mix of 4-, 2-, 2- and 1-tap workgroups
+    const int cls = SPARSE ? bid % a.nclasses : 0;
+    if (SPARSE) bid /= a.nclasses;
     const int ct = bid % a.cout_tiles; bid /= a.cout_tiles;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y; bid /= a.tiles_y;
     const int n = bid;
+    const int ntaps = SPARSE ? a.cls_ntaps[cls] : 9;
     const int TW = 1 << a.tw_log2, TH = kTilePix >> a.tw_log2;
     const int oh0 = ty * TH, ow0 = tx * TW;        // output tile origin
     const int ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;  // input halo origin
@@ -148,9 +160,18 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv3x3_mfma_kernel(
                 if (moff[k] >= 0) mreg[k] = *(const uint4*)(xmask + moff[k] + c0);
             }
         }
+        if constexpr (SPARSE) {                    // 1, 2 or 4 taps: only their slabs travel
+            wr0 = *(const uint4*)(wsrc + a.cls_tap_w[cls][0] * wtap_stride + c0);
+            if (ntaps > 1) wr1 = *(const uint4*)(wsrc + a.cls_tap_w[cls][1] * wtap_stride + c0);
+            if (ntaps > 2) {
+                wr2 = *(const uint4*)(wsrc + a.cls_tap_w[cls][2] * wtap_stride + c0);
+                wr3 = *(const uint4*)(wsrc + a.cls_tap_w[cls][3] * wtap_stride + c0);
+            }
+        } else {
 #define WU_LOADW(t) wr##t = *(const uint4*)(wsrc + (t) * wtap_stride + c0);
-        WU_REP9(WU_LOADW)
+            WU_REP9(WU_LOADW)
 #undef WU_LOADW
+        }
     };
     auto store_chunk = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -163,7 +184,13 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv3x3_mfma_kernel(
             }
         }
 #define WU_STOREW(t) *(uint4*)(w_lds + (t) * (kBN * kChunkBytes) + wdst) = wr##t;
-        WU_REP9(WU_STOREW)
+        if constexpr (SPARSE) {
+            WU_STOREW(0)
+            if (ntaps > 1) { WU_STOREW(1) }
+            if (ntaps > 2) { WU_STOREW(2) WU_STOREW(3) }
+        } else {
+            WU_REP9(WU_STOREW)
+        }
 #undef WU_STOREW
     };
 
@@ -176,15 +203,11 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv3x3_mfma_kernel(
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         if (c + 1 < nchunks) load_chunk((c + 1) * kChunkElems);
-#pragma unroll 1
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int tap = kh * 3 + kw;
+        auto tap_mma = [&](int hoff_tap, int slab) __attribute__((always_inline)) {
             int aoff[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) aoff[mi] = swz_off(apix[mi] + kh * a.halo_w + kw, lh);
-            const char* wt = w_lds + tap * (kBN * kChunkBytes);
+            for (int mi = 0; mi < 2; ++mi) aoff[mi] = swz_off(apix[mi] + hoff_tap, lh);
+            const char* wt = w_lds + slab * (kBN * kChunkBytes);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 uint4 af[2], bf[2];
@@ -197,6 +220,15 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv3x3_mfma_kernel(
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) Mma<T>::run(acc[mi][ni], af[mi], bf[ni]);
             }
+        };
+        if constexpr (SPARSE) {
+#pragma unroll 1
+            for (int t = 0; t < ntaps; ++t) tap_mma(a.cls_tap_dy[cls][t] * a.halo_w + a.cls_tap_dx[cls][t], t);
+        } else {
+#pragma unroll 1
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) tap_mma(kh * a.halo_w + kw, kh * 3 + kw);
         }
         __syncthreads();
         if (c + 1 < nchunks) {
@@ -232,27 +264,31 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv3x3_mfma_kernel(
     else epi_write(std::integral_constant<int, WU_ACT_NONE>{});
     __syncthreads();
     constexpr int kSlotsPerRow = kBN * (int)sizeof(T) / 16;  // 8 (bf16) / 16 (fp32)
-    T* yout = (T*)a.y + (size_t)n * a.Ho * a.Wo * a.ldy + co0;
+    const int OHW = SPARSE ? a.OH * a.OW : a.Ho * a.Wo;
+    T* yout = (T*)a.y + (size_t)n * OHW * a.ldy + co0;
 #pragma unroll
     for (int k = 0; k < kTilePix * kSlotsPerRow / 256; ++k) {
         const int q = tid + 256 * k;
         const int r = q / kSlotsPerRow, s = q % kSlotsPerRow;
         const int oh = oh0 + (r >> a.tw_log2), ow = ow0 + (r & (TW - 1));
-        if (oh < a.Ho && ow < a.Wo) {
+        // where the pixel lands: itself, or (SPARSE) its site in the strided output image
+        const int ph = SPARSE ? oh * a.osy + a.cls_ooy[cls] : oh, pw = SPARSE ? ow * a.osx + a.cls_oox[cls] : ow;
+        const int PW = SPARSE ? a.OW : a.Wo;
+        if (oh < a.Ho && ow < a.Wo && (!SPARSE || (ph < a.OH && pw < a.OW))) {
             uint4 v = *(const uint4*)(smem + r * kRow + s * 16);
             if (a.egate) {
-                const T* eg = (const T*)a.egate + ((size_t)n * a.Ho * a.Wo + (size_t)(oh * a.Wo + ow)) * a.ldegate + co0 + s * (16 / (int)sizeof(T));
+                const T* eg = (const T*)a.egate + ((size_t)n * OHW + (size_t)(ph * PW + pw)) * a.ldegate + co0 + s * (16 / (int)sizeof(T));
                 v = gate16<T>(v, *(const uint4*)eg, a.egate_act);
             }
-            *(uint4*)(yout + (size_t)(oh * a.Wo + ow) * a.ldy + s * (16 / (int)sizeof(T))) = v;
+            *(uint4*)(yout + (size_t)(ph * PW + pw) * a.ldy + s * (16 / (int)sizeof(T))) = v;
         }
     }
 }
 
-template <typename T, int STRIDE, bool MASKED>
+template <typename T, int STRIDE, bool MASKED, bool SPARSE = false>
 int launch_conv(const ConvArgs& a, size_t lds_bytes, int grid, hipStream_t s) {
     constexpr int NH = STRIDE == 1 ? 7 : 19;  // staging items per thread: halo pixels x 4 slots / 256 (stride 2: up to 129 x 9 halo pixels)
-    auto kern = conv3x3_mfma_kernel<T, STRIDE, MASKED, NH>;
+    auto kern = conv3x3_mfma_kernel<T, STRIDE, MASKED, NH, SPARSE>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -263,6 +299,52 @@ int launch_conv(const ConvArgs& a, size_t lds_bytes, int grid, hipStream_t s) {
 }
 
 }  // namespace
+
+int conv_s2_dgrad_parity_launch(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx, const void* egate, int ldegate, int egate_act,
+                                int N, int H, int W, int Cin, int Cout, int dtype, hipStream_t s) {
+    const int esz = dtype == WU_BF16 ? 2 : 4;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    ConvArgs a;
+    a.x = dy; a.mask = nullptr; a.w = w_dgrad; a.bias = nullptr; a.y = dx; a.egate = egate;
+    a.ldx = lddy; a.ldmask = 0; a.ldy = lddx; a.ldegate = ldegate; a.egate_act = egate_act;
+    a.N = N; a.H = Ho; a.W = Wo; a.Ho = Ho; a.Wo = Wo;
+    a.Cin = Cout;                       // the GEMM's K: the forward conv's output channels
+    a.Cout = Cin;                       // ... and its N: the forward conv's input channels
+    a.act = WU_ACT_NONE; a.mask_act = WU_ACT_NONE;
+    int twl = 5;
+    while (twl > 2 && (1 << (twl - 1)) >= Wo) --twl;
+    a.tw_log2 = twl;
+    const int TW = 1 << twl, TH = kTilePix >> twl;
+    a.tiles_x = cdiv(Wo, TW); a.tiles_y = cdiv(Ho, TH); a.cout_tiles = Cin / kBN;
+    a.halo_w = TW + 2; a.halo_h = TH + 2; a.halo_pix = a.halo_w * a.halo_h;
+    if (a.halo_pix > 7 * 256 / 4) return -1;
+    size_t lds = (size_t)a.halo_pix * kChunkBytes + 9 * kBN * kChunkBytes;
+    const size_t epi = (size_t)kTilePix * (kBN * esz + 16);
+    if (epi > lds) lds = epi;
+    const long long grid = (long long)N * a.tiles_x * a.tiles_y * a.cout_tiles;
+    if (grid >= (1ll << 31)) return -1;
+    a.osy = a.osx = 2; a.OH = H; a.OW = W;
+    a.nclasses = 4;
+    for (int c = 0; c < 4; ++c) {
+        const int p = c < 2 ? 1 : 0, q = (c == 0 || c == 2) ? 1 : 0;
+        // forward taps reaching input parity p: kh = 1 from output row i (halo row 1); kh = 0 from row i + 1 (halo row 2), kh = 2 from row i
+        const int nk_y = p ? 2 : 1, nk_x = q ? 2 : 1;
+        const int khs[2] = {p ? 0 : 1, 2}, dys[2] = {p ? 2 : 1, 1};
+        const int kws[2] = {q ? 0 : 1, 2}, dxs[2] = {q ? 2 : 1, 1};
+        a.cls_ntaps[c] = nk_y * nk_x;
+        for (int iy = 0; iy < nk_y; ++iy)
+            for (int ix = 0; ix < nk_x; ++ix) {
+                const int t = iy * nk_x + ix;
+                a.cls_tap_dy[c][t] = dys[iy]; a.cls_tap_dx[c][t] = dxs[ix];
+                a.cls_tap_w[c][t] = 8 - (khs[iy] * 3 + kws[ix]);       // the rotated pack keeps forward tap (kh, kw) in slab 8 - (3 kh + kw)
+            }
+        a.cls_ooy[c] = p; a.cls_oox[c] = q;
+    }
+    if (4 * grid >= (1ll << 31)) return -1;
+    if (dtype == WU_BF16) launch_conv<bf16_t, 1, false, true>(a, lds, (int)(4 * grid), s);
+    else launch_conv<float, 1, false, true>(a, lds, (int)(4 * grid), s);
+    return 0;
+}
 
 extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                               int N, int H, int W, int Cin, int Cout, int stride, int act,

@@ -4,6 +4,7 @@
 // MFMA kernel does the rest.  3/4 of that GEMM's K is structurally zero; the stride-2 convs are ~2 % of
 // a GAN step's FLOPs, so the dedicated 4-parity-class kernel is left for a later round.
 #include "wu_common.h"
+#include "conv_internal.h"
 
 namespace {
 template <typename T>
@@ -39,13 +40,27 @@ extern "C" int wu_conv3x3_s2_dgrad(const void* dy, int lddy, const void* y, int 
                                    int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
     const int esz = dtype == WU_BF16 ? 2 : 4;
     WU_REQUIRE(Cout % (16 / esz) == 0 && ((uintptr_t)dy % 16) == 0 && (lddy * esz) % 16 == 0, "conv3x3_s2_dgrad: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    // Round 4: a pre-gated dY (the autograd nodes gate it first) goes through four sparse-tap convs, one per parity class of the input
+    // site (conv_internal.h): no zero-stuffed copy, 9 instead of 36 tap products.  A dY that still needs its gate keeps the scatter path.
+    if (!y && g_wu_opt[WU_OPT_S2_DGRAD_PARITY] && Cin % 64 == 0 && Cout % (64 / esz) == 0 && ((uintptr_t)dx % 16) == 0 && (lddx * esz) % 16 == 0 &&
+        ((uintptr_t)w_dgrad % 16) == 0 && (size_t)H * W * (size_t)lddx < (1ull << 31)) {
+        if (egate) WU_REQUIRE(((uintptr_t)egate % 16) == 0 && (ldegate * esz) % 16 == 0 && ldegate >= Cin, "conv3x3_s2_dgrad: bad egate");
+        wu_prof_pre(WU_FAM_CONV_S2, s);
+        const int rc = conv_s2_dgrad_parity_launch(dy, lddy, w_dgrad, dx, lddx, egate, ldegate, egate_act, N, H, W, Cin, Cout, dtype, s);
+        if (rc == 0) {
+            const double pix = (double)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
+            wu_prof_post(WU_FAM_CONV_S2, s, 2.0 * pix * Cout * 9.0 * Cin, (pix * Cout + (double)N * H * W * Cin + 9.0 * Cin * Cout) * esz);
+            WU_LAUNCH_CHECK("conv3x3_s2_dgrad(parity)");
+            return 0;
+        }
+    }
     WU_REQUIRE(workspace && ((uintptr_t)workspace % 16) == 0 && workspace_bytes >= wu_conv3x3_s2_dgrad_workspace(N, H, W, Cout, dtype),
                "conv3x3_s2_dgrad: workspace too small");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long total = (long long)N * H * W * (Cout / (16 / esz));
     long long g = (total + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
-    hipStream_t s = (hipStream_t)stream;
     if (dtype == WU_BF16)
         hipLaunchKernelGGL(upsample_zero_gate_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy_, act, (bf16_t*)workspace, N, H, W, Ho, Wo, Cout);
     else

@@ -42,7 +42,7 @@ template <typename T> __device__ __forceinline__ int lds_off(int row, int xc, in
 }
 
 template <typename T, int STRIDE, int P>
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv3x3_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RB = WTraits<T>::kRowBytes;
     constexpr int SLOTS = RB / 16;            // 16-B slots per pixel row (64 channels)
@@ -65,7 +65,90 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradArgs a
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     float bsum = 0.f;
 
+    // Stride 2 (round 4): the next tile's operands travel global -> REGISTERS under this tile's MFMAs and are written to LDS between two
+    // barriers.  (The X halo of a stride-2 tile is 4x the stride-1 one -- 75 KiB + 16 KiB of dY, one workgroup per CU -- and used to be
+    // staged synchronously in front of every tile's MFMAs: nothing overlapped, 117-190 TFLOP/s.)  Tile-invariant item descriptors:
+    // X item k of this thread = halo pixel (hy, hx), 16-byte slot sx; dY item k = tile pixel (ry, rx), slot sd.
+    // staging items per thread: halo pixels x slots / 256 -- at most 585 x 8 (bf16, P = 128) / 325 x 16 (fp32, P = 64); the host checks
+    constexpr int NX = STRIDE == 2 ? (sizeof(T) == 2 ? 19 : 21) : 1, ND = STRIDE == 2 ? (P * SLOTS + 255) / 256 : 1;
+    int xd[NX], dd[ND];                      // packed (hy << 20 | hx << 8 | slot), -1: no such item
+    uint4 xr[NX], dr[ND], yr[ND];
+    unsigned xok = 0, dok = 0;
+    if constexpr (STRIDE == 2) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int item = tid + 256 * k, p_ = item / SLOTS, s_ = item % SLOTS;
+            const int hy = p_ / a.halo_w, hx = p_ - hy * a.halo_w;
+            xd[k] = p_ < a.halo_pix ? (hy << 20 | hx << 8 | s_) : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            const int item = tid + 256 * k, r_ = item / SLOTS, s_ = item % SLOTS;
+            dd[k] = item < P * SLOTS ? ((r_ >> a.tw_log2) << 20 | (r_ & (TW - 1)) << 8 | s_) : -1;
+        }
+    }
+    auto tile_origin = [&](int tile, int& n, int& oh0, int& ow0) __attribute__((always_inline)) {
+        int tt = tile;
+        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
+        const int ty = tt % a.tiles_y;
+        n = tt / a.tiles_y;
+        oh0 = ty * TH; ow0 = tx * TW;
+    };
+    auto prefetch = [&](int tile) __attribute__((always_inline)) {       // STRIDE == 2: unconditional loads from clamped coordinates
+        int n, oh0, ow0;
+        tile_origin(tile, n, oh0, ow0);
+        const int ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
+        const T* xb = (const T*)a.x + (size_t)n * a.H * a.W * a.ldx + cib * 64;
+        const T* dyb = (const T*)a.dy + (size_t)n * a.Ho * a.Wo * a.lddy + cob * 64;
+        const T* yb = a.y ? (const T*)a.y + (size_t)n * a.Ho * a.Wo * a.ldy + cob * 64 : nullptr;
+        xok = 0; dok = 0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int hy = xd[k] >> 20, hx = (xd[k] >> 8) & 0xfff, s_ = xd[k] & 0xff;
+            const int ih = ih0 + hy, iw = iw0 + hx;
+            if (xd[k] >= 0 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) xok |= 1u << k;
+            xr[k] = *(const uint4*)(xb + (size_t)(min(max(ih, 0), a.H - 1) * a.W + min(max(iw, 0), a.W - 1)) * a.ldx + s_ * E);
+        }
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            const int ry = dd[k] >> 20, rx = (dd[k] >> 8) & 0xfff, s_ = dd[k] & 0xff;
+            const int oh = oh0 + ry, ow = ow0 + rx;
+            if (dd[k] >= 0 && oh < a.Ho && ow < a.Wo) dok |= 1u << k;
+            const size_t o = (size_t)(min(oh, a.Ho - 1) * a.Wo + min(ow, a.Wo - 1));
+            dr[k] = *(const uint4*)(dyb + o * a.lddy + s_ * E);
+            if (yb) yr[k] = *(const uint4*)(yb + o * a.ldy + s_ * E);
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {                // registers -> LDS (zero padding as lane masks)
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            if (xd[k] >= 0) {
+                const int item = tid + 256 * k, p_ = item / SLOTS, hx = (xd[k] >> 8) & 0xfff, s_ = xd[k] & 0xff;
+                const uint32_t m = (xok >> k) & 1u ? 0xffffffffu : 0u;
+                *(uint4*)(x_lds + lds_off<T>(p_, hx, s_ * 16)) = make_uint4(xr[k].x & m, xr[k].y & m, xr[k].z & m, xr[k].w & m);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            if (dd[k] >= 0) {
+                const int item = tid + 256 * k, r_ = item / SLOTS, s_ = dd[k] & 0xff;
+                uint4 w_ = dr[k];
+                if (a.y) w_ = gate16<T>(w_, yr[k], a.act);
+                const uint32_t m = (dok >> k) & 1u ? 0xffffffffu : 0u;
+                *(uint4*)(dy_lds + lds_off<T>(r_, r_, s_ * 16)) = make_uint4(w_.x & m, w_.y & m, w_.z & m, w_.w & m);
+            }
+        }
+    };
+    if constexpr (STRIDE == 2) {
+        if (split < a.ntiles) prefetch(split);
+    }
+
     for (int tile = split; tile < a.ntiles; tile += a.splits) {
+        if constexpr (STRIDE == 2) {
+            commit();
+            __syncthreads();
+            if (tile + a.splits < a.ntiles) prefetch(tile + a.splits);
+        } else {
         int tt = tile;
         const int tx = tt % a.tiles_x; tt /= a.tiles_x;
         const int ty = tt % a.tiles_y;
@@ -134,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradArgs a
             }
         }
         __syncthreads();
+        }
 
         // ---- bias gradient: column sums of the dY' tile (ci-block 0 only) ----
         if (cib == 0 && a.bslab) {
@@ -364,6 +448,7 @@ extern "C" int wu_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy
     const WPlan p = wgrad_plan(N, H, W, Cin, Cout, stride, dtype);
     WU_REQUIRE(workspace && workspace_bytes >= p.ws && ((uintptr_t)workspace % 16) == 0, "conv3x3_wgrad: workspace too small (%zu < %zu)", workspace_bytes, p.ws);
     WU_REQUIRE(p.lds <= 160 * 1024, "conv3x3_wgrad: LDS %zu", p.lds);
+    if (stride == 2) WU_REQUIRE(p.halo_w * p.halo_h * (dtype == WU_BF16 ? 8 : 16) <= (dtype == WU_BF16 ? 19 : 21) * 256, "conv3x3_wgrad: halo %d x %d exceeds the stride-2 staging registers", p.halo_w, p.halo_h);
     WgradArgs a;
     a.x = x; a.dy = dy; a.y = y;
     a.slab = (float*)workspace;

@@ -10,3 +10,10 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
                    void* pool = nullptr, int ldpool = 0,
                    // ReLU gate as bits (wu_conv3x3_fwd_bits): written by a forward with act == RELU / read by a data-gradient pass
                    void* gate_bits_out = nullptr, const void* egate_bits = nullptr);
+
+// Data gradient of a stride-2 conv as FOUR sparse-tap stride-1 convs, one per parity class (p, q) of the input site (conv3x3_mfma.hip):
+// site (2i + p, 2j + q) receives forward taps kh in {1} (p = 0) or {0, 2} (p = 1) only, so the classes take 1 / 2 / 2 / 4 of the nine
+// tap products -- no zero-stuffed copy of dY, no multiplication by structural zeros.  dy: (N, Cout, Ho, Wo) pre-gated; w_dgrad: the
+// rotated 9-slab pack [tap'][Cin][Cout]; dx: (N, Cin, H, W), optionally gated by act'(egate) in the epilogue.
+int conv_s2_dgrad_parity_launch(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx, const void* egate, int ldegate, int egate_act,
+                                int N, int H, int W, int Cin, int Cout, int dtype, hipStream_t s);
