@@ -289,6 +289,19 @@ int wu_conv1x1_fwd(const void* x, int ldx, const void* w, const float* bias, con
                    void* y, int ldy, int N, int Hc, int Wc, int in_stride, int Hin, int Win,
                    int out_stride, int Hout, int Wout, int Cin, int Cout, int act,
                    const void* egate, int ldegate, int egate_act, int dtype, void* stream);
+/* Two chained 1x1 convs in ONE launch (bf16): y1 = act1(wa . x + bias_a + res) * act'(gate1), y2 = act2(wb . y1 + bias_b) * act'(gate2),
+ * both stored.  x: [M][K1] (pixel stride ldx); wa = the [C1][K1] weight and wb = the [C2][C1] weight in MFMA-FRAGMENT ORDER
+ * [cout / 32][k / 16][k half (2)][cout row (32)][8 elements] (a wave's 16-byte A fragments of one (cout block, K step) are 1 KiB
+ * contiguous: weights are streamed straight into registers); res / gate1 with y1's geometry, gate2 with y2's; any of bias_a, bias_b,
+ * res, gate1, gate2 may be NULL.  Forward: torchvision Bottleneck conv3 + bn3 + residual + ReLU of one block followed
+ * by conv1 + bn1 + ReLU of the next (classifier.py:106-112 / estimator.py:143-151 build resnet101); backward: conv1^T of a block (+ the
+ * identity-path gradient, gated by the block boundary's ReLU) followed by conv3^T of the previous block (gated by its 3x3 conv's ReLU).
+ * Bit-identical to two wu_conv1x1_fwd calls.  Shapes: wu_conv1x1_chain_supported(K1, C1, C2, dtype) != 0. */
+int wu_conv1x1_chain_supported(int K1, int C1, int C2, int dtype);
+int wu_conv1x1_chain(const void* x, int ldx, const void* wa, const float* bias_a, const void* res, int ldres, int act1,
+                     const void* gate1, int ldg1, int gate1_act, void* y1, int ldy1,
+                     const void* wb, const float* bias_b, int act2, const void* gate2, int ldg2, int gate2_act, void* y2, int ldy2,
+                     long long M, int K1, int C1, int C2, int dtype, void* stream);
 /* Stem: nn.Conv2d(3, 64, 7, stride=2, padding=3) + folded BN + ReLU from the NCHW fp32 image to NHWC `dtype`
  * (N, Ho, Wo, 64), Ho = (H-1)/2 + 1; w: OIHW fp32 [64][3][7][7], bias [64] (may be NULL). */
 int wu_stem7x7_fwd(const float* x_nchw, const float* w_oihw, const float* bias, void* y, int ldy,

@@ -227,3 +227,85 @@ def test_stride2_dgrad_parity_classes(precision, shape, gated):
         assert not torch.isnan(res[opt]).any(), f"path {opt} left sites unwritten"
         err = (res[opt] - want).abs().max().item()
         assert err <= tol, f"path {opt}: {err} vs tolerance {tol}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# two chained pointwise convs in one launch (csrc/resnet.hip conv1x1_chain_kernel; torchvision Bottleneck, classifier.py:106-112)
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(37, 64, 256, 64), (300, 128, 512, 128), (64, 256, 1024, 256), (33, 256, 1024, 512), (5, 64, 256, 128), (100, 128, 512, 64)])
+@pytest.mark.parametrize("mode", ["forward", "backward"])
+def test_conv1x1_chain_is_bitwise_two_pointwise_launches(shape, mode):
+    """wu_conv1x1_chain against two wu_conv1x1_fwd calls on the same operands -- forward form (bias + residual + ReLU, then bias + ReLU)
+    and backward form (residual + ReLU gate, then ReLU gate) -- with a ragged row count (rows past M in the last 32-row tile), every K1
+    the estimator uses and a C2 smaller than a wave's share: both outputs BIT-IDENTICAL, and within bf16 rounding of float64."""
+    from wu import _lib, resnet as RN
+    from wu.layout import empty_nhwc
+    m, k1, c1, c2 = shape
+    dev, bf = _dev(), torch.bfloat16
+    n, h, w = 1, 1, m
+    def t(c, seed, lo=-1.0, hi=1.0):
+        return _rand((n, h, w, c), seed, lo, hi).to(bf).to(dev).permute(0, 3, 1, 2)
+    x = t(k1, 1)
+    wa = (_rand((c1, k1), 2, -1, 1) / k1 ** 0.5).to(bf).to(dev)
+    wb = (_rand((c2, c1), 3, -1, 1) / c1 ** 0.5).to(bf).to(dev)
+    res, g1, g2 = t(c1, 4), t(c1, 5), t(c2, 6)
+    ba, bb = _rand((c1,), 7).to(dev), _rand((c2,), 8).to(dev)
+    RELU, NONE = RN.RELU, RN.NONE
+    y1a, y2a = empty_nhwc(n, c1, h, w, bf, dev), empty_nhwc(n, c2, h, w, bf, dev)
+    y1b, y2b = empty_nhwc(n, c1, h, w, bf, dev), empty_nhwc(n, c2, h, w, bf, dev)
+    for y in (y1a, y2a, y1b, y2b):
+        y.fill_(float("nan"))
+    assert _lib.load().wu_conv1x1_chain_supported(k1, c1, c2, _lib.BF16)
+    if mode == "forward":
+        RN.conv1x1_chain(x, RN.frag_pack(wa), ba, res, RELU, None, NONE, y1a, RN.frag_pack(wb), bb, RELU, None, NONE, y2a)
+        RN.conv1x1(x, wa, ba, y1b, RELU, residual=res)
+        RN.conv1x1(y1b, wb, bb, y2b, RELU)
+        r1 = torch.relu(x.double().cpu().permute(0, 2, 3, 1) @ wa.double().cpu().t() + ba.double().cpu() + res.double().cpu().permute(0, 2, 3, 1))
+        r2 = torch.relu(y1b.double().cpu().permute(0, 2, 3, 1) @ wb.double().cpu().t() + bb.double().cpu())
+    else:
+        RN.conv1x1_chain(x, RN.frag_pack(wa), None, res, NONE, g1, RELU, y1a, RN.frag_pack(wb), None, NONE, g2, RELU, y2a)
+        RN.conv1x1(x, wa, None, y1b, NONE, residual=res, egate=g1, egate_act=RELU)
+        RN.conv1x1(y1b, wb, None, y2b, NONE, egate=g2, egate_act=RELU)
+        r1 = (x.double().cpu().permute(0, 2, 3, 1) @ wa.double().cpu().t() + res.double().cpu().permute(0, 2, 3, 1)) * (g1.double().cpu().permute(0, 2, 3, 1) > 0)
+        r2 = (y1b.double().cpu().permute(0, 2, 3, 1) @ wb.double().cpu().t()) * (g2.double().cpu().permute(0, 2, 3, 1) > 0)
+    torch.cuda.synchronize()
+    assert not torch.isnan(y1a.float()).any() and not torch.isnan(y2a.float()).any()
+    assert torch.equal(y1a, y1b), f"y1 differs from the stand-alone launch: {(y1a.float() - y1b.float()).abs().max().item():.3e}"
+    assert torch.equal(y2a, y2b), f"y2 differs from the stand-alone launch: {(y2a.float() - y2b.float()).abs().max().item():.3e}"
+    for got, want in ((y1a, r1), (y2a, r2)):
+        err = (got.double().cpu().permute(0, 2, 3, 1) - want).abs().max().item()
+        assert err <= 1.2e-2 * max(1.0, want.abs().max().item()), err
+
+
+def test_estimator_chained_pointwise_is_bitwise_the_unchained_network():
+    """The whole bf16 ResNet-101 (33 Bottlenecks, 64x64 input) with and without the chained launches: outputs and the input gradient
+    bit-identical; under no_grad as well (the reference's three no-grad estimator calls, t_cls_train.py:237,297,424)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import resnet_ref as R
+    from wu import resnet as RN
+    dev, nc = _dev(), 5
+    p = R.make_resnet101_params(nc, 4)
+    x = _rand((3, 3, 64, 96), 9)
+    wsum = _rand((3, nc), 10).to(dev)
+    res = {}
+    saved = (RN.CHAIN, RN.CHAIN_MIN_K1)
+    try:
+        for chain in (False, True):
+            RN.CHAIN, RN.CHAIN_MIN_K1 = chain, 64           # every pair the kernel supports, not only the ones the default picks
+            est = RN.ResNet101Estimator(nc, precision="bf16")
+            est.load_state_dict(p, strict=False)
+            est = est.to(dev)
+            xd = x.to(dev).requires_grad_(True)
+            out = est(xd)
+            (out * wsum).sum().backward()
+            with torch.no_grad():
+                out_ng = est(x.to(dev))
+            torch.cuda.synchronize()
+            res[chain] = (out.detach().clone(), xd.grad.clone(), out_ng.clone())
+    finally:
+        RN.CHAIN, RN.CHAIN_MIN_K1 = saved
+    for a, b, name in zip(res[False], res[True], ("outputs", "input gradient", "no-grad outputs")):
+        assert torch.isfinite(a).all() and a.abs().max().item() > 0
+        assert torch.equal(a, b), f"{name}: chained != unchained (max {(a - b).abs().max().item():.3e})"

@@ -323,6 +323,180 @@ __global__ __launch_bounds__(256, TM == 256 ? 2 : (TM == 128 ? 3 : 4)) void conv
 }
 
 // =================================================================================================
+// TWO chained 1x1 convs in one launch (round 4, bf16):
+//     y1 = act1(wa . x  + bias_a + res) * act'(gate1)        x: [M][K1], wa: [C1][K1], y1: [M][C1]  (stored)
+//     y2 = act2(wb . y1 + bias_b)       * act'(gate2)        wb: [C2][C1],             y2: [M][C2]  (stored)
+// Forward of the Bottleneck chain (classifier.py:106-112 / torchvision Bottleneck): conv3 + bn3 + residual + ReLU of block i, then
+// conv1 + bn1 + ReLU of block i + 1 -- the 1024-channel block output never comes back from memory for the next block's first conv.
+// Backward, the mirror image: conv1^T of block i + 1 (+ identity-path gradient, ReLU gate of the block boundary) then conv3^T of block i
+// (ReLU gate of its 3x3 conv's output).  The estimator launched 210 pointwise GEMMs per GAN iteration at 24-80 us each although each is
+// 1-4 GFLOP: a dependent launch costs its drain / write-back / ramp (6-10 us) and one HBM round trip of its input; a pair here is one.
+//
+// One 512-thread workgroup (8 waves, two per SIMD) = 32 GEMM rows, all of C1 and C2.  Every weight element is used for 32 rows only, so
+// the weight STREAM (64 B/clk per CU from L2; 1 MB per workgroup for 256 -> 1024 -> 256) bounds the kernel, and what it needs is bytes in
+// flight: the weights are read as MFMA A FRAGMENTS straight into registers from a fragment-ordered pack ([cout / 32][k / 16][64 lanes]
+// x 16 bytes, made once per frozen plan by the host: every wave-level load is 1 KiB contiguous -- the first version read row-major weights
+// in fragment shape, 32 rows x 32 bytes per instruction, and ran 1.6x SLOWER than the two launches it replaces), 16 fragments per wave =
+// 128 KiB per CU requested ahead of the MFMAs that use them.
+// Stage 1: wave w owns couts {32 (w + 8 j)}; the 32 x K1 x-tile is its MFMA B operand, in REGISTERS (K1 / 16 fragments, loaded once).
+// The finished y1 block goes to global AND, as bf16, to a swizzled LDS image [32][C1] (16-byte slot XOR (row & 15): the 32 rows of a
+// fragment read hit 16 different slots per 16-lane group).  Stage 2 (after ONE barrier): wave w owns couts {32 (w + 8 j)} of C2, B
+// fragments from the LDS image.  Accumulation order = the K order of conv1x1_mfma_kernel: bit-identical to the two separate launches.
+constexpr int kChainWaves = 8;
+// GATED = false: the forward pair (bias_a, res, bias_b present; no gates).  GATED = true: the backward pair (res, gate1, gate2 present; no
+// bias).  Compile-time, and the prefetches below are UNCONDITIONAL (the last block re-requests itself): behind a run-time `if` the
+// compiler cannot count the loads in flight and waits for all of them in front of the MFMAs (measured on the first version: vmcnt(1)
+// right after the 16 prefetch loads).
+template <int K1, bool GATED>
+__global__ __launch_bounds__(64 * kChainWaves, 1) void conv1x1_chain_kernel(const bf16_t* __restrict__ x, int ldx, const uint4* __restrict__ wa,
+        const float* __restrict__ bias_a, const bf16_t* __restrict__ res, int ldres, int act1, const bf16_t* __restrict__ gate1, int ldg1, int gate1_act,
+        bf16_t* __restrict__ y1, int ldy1, const uint4* __restrict__ wb, const float* __restrict__ bias_b, int act2,
+        const bf16_t* __restrict__ gate2, int ldg2, int gate2_act, bf16_t* __restrict__ y2, int ldy2, long long M, int C1, int C2) {
+    constexpr int KS1 = K1 / 16;                               // MFMA K steps of stage 1
+    constexpr int NW = kChainWaves;
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // y1 tile: [32][C1] bf16, swizzled
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * 32;
+    const long long mrow = m0 + l31;
+    const bool ok = mrow < M;
+    const long long prow = ok ? mrow : M - 1;                  // clamped: loads unconditional, stores skipped
+    const int pitch = C1 * 2;
+
+    // ---- the x tile as B fragments: lane (row l31, k half lh) holds 8 consecutive k of K step ks ----
+    uint4 xf[KS1];
+    {
+        const bf16_t* xp = x + prow * ldx + 8 * lh;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) xf[ks] = *(const uint4*)(xp + 16 * ks);
+    }
+    // epilogue of one 32-cout block in the transposed-accumulator layout (a lane: 16 couts of row l31): pairs the half-waves'
+    // 4-channel groups (v_permlane32_swap) so that residual / gate / output move as 16-byte items
+    auto epilogue = [&](const f32x16_t& acc, int co0, const float* __restrict__ bias, bool has_r, const uint4 (&rq)[2], int act,
+                        const uint4 (&gq)[2], int gact, bf16_t* __restrict__ yo, int ldy, bool to_lds) __attribute__((always_inline)) {
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            float lo[4], hi[4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int g = 2 * gp + e;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (!GATED) bv = *(const float4*)(bias + co0 + 8 * g + 4 * lh);
+                float* d = e ? hi : lo;
+                d[0] = acc[4 * g + 0] + bv.x; d[1] = acc[4 * g + 1] + bv.y; d[2] = acc[4 * g + 2] + bv.z; d[3] = acc[4 * g + 3] + bv.w;
+            }
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo[i]), __float_as_uint(hi[i]), false, false);
+                o[i] = __uint_as_float(sw[0]);
+                o[4 + i] = __uint_as_float(sw[1]);
+            }
+            if (has_r) {
+                float rv[8];
+                unpack16<bf16_t>(rq[gp], rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += rv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = act_apply(o[e], act);
+            if constexpr (GATED) {
+                float gv[8];
+                unpack16<bf16_t>(gq[gp], gv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = act_gate(o[e], gv[e], gact);
+            }
+            const uint4 pk = pack16<bf16_t>(o);
+            const int c = co0 + 16 * gp + 8 * lh;                 // this lane's 8 consecutive channels
+            if (ok) *(uint4*)(yo + mrow * ldy + c) = pk;
+            if (to_lds) *(uint4*)(smem + l31 * pitch + ((((c >> 3) ^ (l31 & 15))) << 4)) = pk;
+        }
+    };
+    // A fragment (cout block cb, K step ks) of a fragment-ordered pack with KS steps per block: 1 KiB contiguous per wave
+    auto load_a = [&](const uint4* __restrict__ w, int cb, int KS, int ks) __attribute__((always_inline)) { return w[((size_t)cb * KS + ks) * 64 + lane]; };
+
+    // ---- stage 1: couts 32 (wave + NW j); C1 / 256 = 1, 2 or 4 blocks per wave ----
+    const int nblk = C1 / (32 * NW);
+    uint4 af[2][16];
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) af[0][ks] = load_a(wa, wave, KS1, ks);
+    auto block1 = [&](auto CUR, int cb, int cb_next) __attribute__((always_inline)) {
+        constexpr int S = decltype(CUR)::value;
+        const int co0 = 32 * cb;
+        uint4 rq[2], gq[2];
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {                       // residual / gate of this block: in flight under its MFMAs
+            rq[gp] = *(const uint4*)(res + prow * ldres + co0 + 16 * gp + 8 * lh);
+            if constexpr (GATED) gq[gp] = *(const uint4*)(gate1 + prow * ldg1 + co0 + 16 * gp + 8 * lh);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) af[S ^ 1][ks] = load_a(wa, cb_next, KS1, ks);       // the next block's fragments (unconditional)
+        f32x16_t acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) PwMma<bf16_t>::run(acc, af[S][ks], xf[ks]);
+        epilogue(acc, co0, bias_a, true, rq, act1, gq, gate1_act, y1, ldy1, true);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int last1 = wave + NW * (nblk - 1);
+    if (nblk == 1) {
+        block1(S0{}, wave, wave);
+    } else {
+        for (int j = 0; j < nblk; j += 2) {
+            const int cb = wave + NW * j;
+            block1(S0{}, cb, cb + NW);
+            block1(S1{}, cb + NW, min(cb + 2 * NW, last1));
+        }
+    }
+    // ---- stage 2: couts 32 (wave + NW j) of C2; K = C1 in groups of 16 K steps (C1 / 256 = 1, 2 or 4 groups) ----
+    const int nb2 = C2 / 32;
+    const int KS2 = C1 / 16, ngrp = KS2 / 16;
+    // the first group of this wave's first block is requested BEFORE the barrier that publishes the y1 image
+#pragma unroll
+    for (int t = 0; t < 16; ++t) af[0][t] = load_a(wb, min(wave, nb2 - 1), KS2, t);
+    __syncthreads();
+    auto group2 = [&](auto CUR, f32x16_t& acc, int cb_next, int g, int g_next) __attribute__((always_inline)) {
+        constexpr int S = decltype(CUR)::value;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) af[S ^ 1][t] = load_a(wb, cb_next, KS2, 16 * g_next + t);     // unconditional
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int slot = 2 * (16 * g + t) + lh;                            // 16-byte slot of (K step, k half) in the row
+            const uint4 bfrag = *(const uint4*)(smem + l31 * pitch + ((slot ^ (l31 & 15)) << 4));
+            PwMma<bf16_t>::run(acc, af[S][t], bfrag);
+        }
+    };
+    for (int cb = wave; cb < nb2; cb += NW) {
+        const int co0 = 32 * cb;
+        const int cbn = min(cb + NW, nb2 - 1);                 // the block whose first group follows this block's last one
+        uint4 rq[2], gq[2];
+        if constexpr (GATED) {
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) gq[gp] = *(const uint4*)(gate2 + prow * ldg2 + co0 + 16 * gp + 8 * lh);
+        }
+        f32x16_t acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        // every block starts with its group 0 in set 0 and ends with the next block's group 0 in set 0
+        if (ngrp == 1) {
+            group2(S0{}, acc, cbn, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) af[0][t] = af[1][t];
+        } else {
+            for (int g = 0; g < ngrp; g += 2) {
+                group2(S0{}, acc, cb, g, g + 1);
+                const bool lastg = g + 2 >= ngrp;
+                group2(S1{}, acc, lastg ? cbn : cb, g + 1, lastg ? 0 : g + 2);
+            }
+        }
+        epilogue(acc, co0, bias_b, false, rq, act2, gq, gate2_act, y2, ldy2, false);
+    }
+}
+
+// =================================================================================================
 // stem: conv 7x7, stride 2, pad 3, 3 -> 64, + bias + ReLU, NCHW fp32 image -> NHWC T
 // =================================================================================================
 // One workgroup = 8 x 32 output pixels x 64 channels: the 21 x 69 x 3 input patch and the [147][64] weights sit in LDS, every
@@ -825,6 +999,56 @@ extern "C" int wu_conv1x1_fwd(const void* x, int ldx, const void* w, const float
     else DISPATCH_T(dtype, hipLaunchKernelGGL((conv1x1_mfma_kernel<T, 256>), dim3((unsigned)grid), dim3(256), 2 * (256 + kTN) * kKB, s, a));
     wu_prof_post(WU_FAM_CONV1X1, s, 2.0 * (double)a.M * Cin * Cout, ((double)a.M * (Cin + Cout * (residual ? 2 : 1)) + (double)Cin * Cout) * esz);
     WU_LAUNCH_CHECK("conv1x1_mfma");
+    return 0;
+}
+
+extern "C" int wu_conv1x1_chain_supported(int K1, int C1, int C2, int dtype) {
+    return (dtype == WU_BF16 && (K1 == 64 || K1 == 128 || K1 == 256) && C1 >= 256 && C1 % 256 == 0 && C1 <= 1024 && C2 >= 32 && C2 % 32 == 0) ? 1 : 0;
+}
+
+extern "C" int wu_conv1x1_chain(const void* x, int ldx, const void* wa, const float* bias_a, const void* res, int ldres, int act1,
+                                const void* gate1, int ldg1, int gate1_act, void* y1, int ldy1,
+                                const void* wb, const float* bias_b, int act2, const void* gate2, int ldg2, int gate2_act, void* y2, int ldy2,
+                                long long M, int K1, int C1, int C2, int dtype, void* stream) {
+    WU_REQUIRE(wu_conv1x1_chain_supported(K1, C1, C2, dtype), "conv1x1_chain: unsupported K1=%d C1=%d C2=%d dtype=%d (ask wu_conv1x1_chain_supported)", K1, C1, C2, dtype);
+    WU_REQUIRE(M > 0 && M < (1ll << 36) && x && wa && wb && y1 && y2, "conv1x1_chain: bad args");
+    // two forms only (compile-time epilogues): forward = bias_a + res + bias_b, no gates; backward = res + gate1 + gate2, no bias
+    const bool gated = gate1 != nullptr;
+    WU_REQUIRE(res && (gated ? (gate2 && !bias_a && !bias_b) : (bias_a && bias_b && !gate2)),
+               "conv1x1_chain: operands must be (bias_a, res, bias_b) [forward pair] or (res, gate1, gate2) [backward pair]");
+    WU_REQUIRE(ldx >= K1 && ldy1 >= C1 && ldy2 >= C2 && (ldx * 2) % 16 == 0 && (ldy1 * 2) % 16 == 0 && (ldy2 * 2) % 16 == 0 &&
+               al16(x) && al16(wa) && al16(wb) && al16(y1) && al16(y2), "conv1x1_chain: bad ld / alignment");
+    if (res) WU_REQUIRE(ldres >= C1 && (ldres * 2) % 16 == 0 && al16(res), "conv1x1_chain: bad residual");
+    if (gate1) WU_REQUIRE(ldg1 >= C1 && (ldg1 * 2) % 16 == 0 && al16(gate1), "conv1x1_chain: bad gate1");
+    if (gate2) WU_REQUIRE(ldg2 >= C2 && (ldg2 * 2) % 16 == 0 && al16(gate2), "conv1x1_chain: bad gate2");
+    if (bias_a) WU_REQUIRE(al16(bias_a), "conv1x1_chain: bias alignment");
+    if (bias_b) WU_REQUIRE(al16(bias_b), "conv1x1_chain: bias alignment");
+    const long long grid = (M + 31) / 32;
+    WU_REQUIRE(grid < (1ll << 31), "conv1x1_chain: grid too large");
+    const size_t lds = (size_t)32 * C1 * 2;
+    hipStream_t s = (hipStream_t)stream;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+#define WU_CHAIN_ATTR(K_, G_) (void)hipFuncSetAttribute((const void*)conv1x1_chain_kernel<K_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
+        WU_CHAIN_ATTR(64, false); WU_CHAIN_ATTR(128, false); WU_CHAIN_ATTR(256, false); WU_CHAIN_ATTR(64, true); WU_CHAIN_ATTR(128, true); WU_CHAIN_ATTR(256, true);
+#undef WU_CHAIN_ATTR
+        attr_set = true;
+    }
+    wu_prof_pre(WU_FAM_CONV1X1, s);
+#define WU_CHAIN(K_) hipLaunchKernelGGL((conv1x1_chain_kernel<K_, G_>), dim3((unsigned)grid), dim3(64 * kChainWaves), lds, s, (const bf16_t*)x, ldx, (const uint4*)wa, bias_a, \
+                                        (const bf16_t*)res, ldres, act1, (const bf16_t*)gate1, ldg1, gate1_act, (bf16_t*)y1, ldy1, (const uint4*)wb, bias_b, act2, \
+                                        (const bf16_t*)gate2, ldg2, gate2_act, (bf16_t*)y2, ldy2, M, C1, C2)
+    if (gated) {
+        constexpr bool G_ = true;
+        if (K1 == 64) WU_CHAIN(64); else if (K1 == 128) WU_CHAIN(128); else WU_CHAIN(256);
+    } else {
+        constexpr bool G_ = false;
+        if (K1 == 64) WU_CHAIN(64); else if (K1 == 128) WU_CHAIN(128); else WU_CHAIN(256);
+    }
+#undef WU_CHAIN
+    wu_prof_post(WU_FAM_CONV1X1, s, 2.0 * (double)M * ((double)K1 * C1 + (double)C1 * C2),
+                 ((double)M * (K1 + C1 * (res ? 2 : 1) + C2) + (double)K1 * C1 + (double)C1 * C2) * 2);
+    WU_LAUNCH_CHECK("conv1x1_chain");
     return 0;
 }
 

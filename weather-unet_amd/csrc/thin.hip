@@ -922,7 +922,7 @@ __global__ __launch_bounds__(256) void img3_conv_kernel(const float* __restrict_
         float q[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) q[p] = act_apply(acc[co][p], ACT);
-        if (ow + 3 < W && (W & 3) == 0) {
+        if (ow + 3 < W && (W & 3) == 0 && (((uintptr_t)y) & 15) == 0) {          // 16-byte stores need an aligned base too (advisor, round 3)
             float4 ov = make_float4(q[0], q[1], q[2], q[3]);
             if (accumulate) { const float4 old = *(const float4*)o; ov.x += old.x; ov.y += old.y; ov.z += old.z; ov.w += old.w; }
             *(float4*)o = ov;
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(256) void img3_wgrad_kernel(const float* __restrict
         img3_stage(xs, x + (size_t)n * 3 * hw, H, W, h0, w0);
         const int oh = h0 + r, ow = w0 + c4;
         float g[3][4];
-        const bool vec = (W & 3) == 0 && oh < H && ow + 3 < W;
+        const bool vec = (W & 3) == 0 && oh < H && ow + 3 < W && ((((uintptr_t)dy) | ((uintptr_t)yact)) & 15) == 0;   // aligned bases (NULL yact: 0)
 #pragma unroll
         for (int co = 0; co < 3; ++co) {
             const size_t o = ((size_t)n * 3 + co) * hw + (size_t)oh * W + ow;

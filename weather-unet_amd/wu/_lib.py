@@ -74,6 +74,8 @@ SIGNATURES = {
     "wu_nhwc_to_nchw_f32": (I, [P, I, P, I, I, I, I, I, P]),
     "wu_nchw_f32_to_nhwc": (I, [P, P, I, I, I, I, I, I, P]),
     "wu_conv1x1_fwd": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, I, I, I, P]),
+    "wu_conv1x1_chain_supported": (I, [I, I, I, I]),
+    "wu_conv1x1_chain": (I, [P, I, P, P, P, I, I, P, I, I, P, I, P, P, I, P, I, I, P, I, ctypes.c_longlong, I, I, I, I, P]),
     "wu_stem7x7_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "wu_stem7x7_dgrad": (I, [P, I, P, P, I, I, I, I, I, P]),
     "wu_maxpool3s2_fwd": (I, [P, I, P, I, P, I, I, I, I, I, P]),

@@ -17,6 +17,8 @@ frozen parameters), so
 ResNet-101 state-dict unchanged; torchvision itself is not needed.  The forward returns RAW outputs (what the scripts call
 ``estimator_``; ``t_cls_train`` wraps it in ``nn.Softmax`` to get ``estimator``).
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -53,6 +55,43 @@ def conv1x1(x, w, bias, y, act=NONE, residual=None, egate=None, egate_act=NONE, 
               y.data_ptr(), nhwc_ld(y), n, hc, wc, in_stride, hin, win, out_stride, hout, wout, cin, cout, act,
               ep, eld, egate_act, dtype_code(x), stream_ptr())
     return y
+
+
+# conv3 + residual + ReLU of a block and conv1 + ReLU of the next in ONE launch (and the mirror-image pair in backward).  OFF by default:
+# measured (round 4, profiles/r04_chain_bench.txt, r04_gan_chain_ab.txt) the chained launch is bit-identical but not faster -- every
+# 32-row workgroup streams both weight matrices (1 MB at layer3) from L2, 256 workgroups at once: 28 us against 30 us for the two launches
+# at layer3, 1.3-1.6x slower at layers 1-2, GAN iteration +0.1 ms (B = 32) / +1.0 ms (B = 64).  WU_RESNET_CHAIN=1 switches it on.
+CHAIN = os.environ.get("WU_RESNET_CHAIN", "0") == "1"
+
+
+# Only where it pays (scratch/bench_chain.py, profiles/r04_chain_bench.txt): the chained launch keeps ONE 512-thread workgroup per CU and
+# is bound by its own serial chain of memory round trips per 32-row tile -- at K1 = 256 (layer3: 8 k rows, 1 MB of weights per pair) it
+# beats the two launches, at K1 = 64 / 128 (131 k / 33 k rows, weights of 64-256 KB) the two bandwidth-bound launches are 1.3-1.6x faster.
+CHAIN_MIN_K1 = int(os.environ.get("WU_RESNET_CHAIN_MIN_K1", "256"))
+
+
+def chain_supported(k1, c1, c2, code):
+    return CHAIN and k1 >= CHAIN_MIN_K1 and bool(_lib.load().wu_conv1x1_chain_supported(int(k1), int(c1), int(c2), int(code)))
+
+
+def frag_pack(w):
+    """[Cout][K] -> MFMA-fragment order [Cout / 32][K / 16][k half][cout row][8]: the 64 lanes' 16-byte A fragments of one (cout block,
+    K step) are 1 KiB contiguous (include/wu_kernels.h, wu_conv1x1_chain)."""
+    co, k = w.shape
+    return w.view(co // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def conv1x1_chain(x, wa, bias_a, res, act1, gate1, gate1_act, y1, wb, bias_b, act2, gate2, gate2_act, y2):
+    """y1 = act1(wa . x + bias_a + res) * act'(gate1);  y2 = act2(wb . y1 + bias_b) * act'(gate2)  (wu_conv1x1_chain): all tensors on
+    one unit-stride pixel grid; wa / wb in fragment order (``frag_pack``)."""
+    n, k1, h, w = x.shape
+    c1, c2 = y1.shape[1], y2.shape[1]
+    ptr = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
+    ld = lambda t: nhwc_ld(t) if t is not None else 0            # noqa: E731
+    _lib.call("wu_conv1x1_chain", x.data_ptr(), nhwc_ld(x), wa.data_ptr(), ptr(bias_a), ptr(res), ld(res), act1, ptr(gate1), ld(gate1), gate1_act,
+              y1.data_ptr(), nhwc_ld(y1), wb.data_ptr(), ptr(bias_b), act2, ptr(gate2), ld(gate2), gate2_act, y2.data_ptr(), nhwc_ld(y2),
+              n * h * w, k1, c1, c2, dtype_code(x), stream_ptr())
+    return y1, y2
 
 
 def stem7x7(x_nchw, w, bias, y, act, code):
@@ -174,7 +213,10 @@ class ResNet101Estimator(nn.Module):
             def pw(conv, bn):
                 w, b = fold(conv, bn)
                 w2 = w.view(w.shape[0], w.shape[1])
-                return {"w": w2.to(dt).contiguous(), "wt": w2.t().to(dt).contiguous(), "b": b}
+                d = {"w": w2.to(dt).contiguous(), "wt": w2.t().to(dt).contiguous(), "b": b}
+                if code == _lib.BF16 and w2.shape[0] % 32 == 0 and w2.shape[1] % 32 == 0:
+                    d["wp"], d["wtp"] = frag_pack(d["w"]), frag_pack(d["wt"])          # MFMA-fragment order (wu_conv1x1_chain)
+                return d
 
             def c3(conv, bn):
                 w, b = fold(conv, bn)
@@ -223,16 +265,25 @@ class ResNetFn(Function):
         cur = maxpool3s2(stem, new(64, h2, w2), amax)                                          # maxpool
         saved = []
         hh, ww = h2, w2
-        for blk in plan["blocks"]:
+        blocks = plan["blocks"]
+        a_next = None                       # conv1 + bn1 + relu of the coming block, when the previous block's chained launch produced it
+        for bi, blk in enumerate(blocks):
             s, planes = blk["stride"], blk["planes"]
-            a = conv1x1(cur, blk["c1"]["w"], blk["c1"]["b"], new(planes, hh, ww), RELU)        # conv1 + bn1 + relu
+            a = a_next if a_next is not None else conv1x1(cur, blk["c1"]["w"], blk["c1"]["b"], new(planes, hh, ww), RELU)   # conv1 + bn1 + relu
             ho, wo = _half(hh, s), _half(ww, s)
             b = K.conv3x3(a, blk["c2"]["w"], blk["c2"]["b"], new(planes, ho, wo), s, RELU)      # conv2 (stride here) + bn2 + relu
             if blk["ds"] is not None:                                                           # downsample: conv1x1 stride s + bn
                 idn = conv1x1(cur, blk["ds"]["w"], blk["ds"]["b"], new(planes * EXPANSION, ho, wo), NONE, in_stride=s)
             else:
                 idn = cur
-            out = conv1x1(b, blk["c3"]["w"], blk["c3"]["b"], new(planes * EXPANSION, ho, wo), RELU, residual=idn)   # conv3 + bn3 + add + relu
+            nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
+            if nxt is not None and "wp" in blk["c3"] and "wp" in nxt["c1"] and chain_supported(planes, planes * EXPANSION, nxt["planes"], code):
+                # conv3 + bn3 + add + relu, then the next block's conv1 + bn1 + relu on the tile that is still on chip
+                out, a_next = conv1x1_chain(b, blk["c3"]["wp"], blk["c3"]["b"], idn, RELU, None, NONE, new(planes * EXPANSION, ho, wo),
+                                            nxt["c1"]["wp"], nxt["c1"]["b"], RELU, None, NONE, new(nxt["planes"], ho, wo))
+            else:
+                out = conv1x1(b, blk["c3"]["w"], blk["c3"]["b"], new(planes * EXPANSION, ho, wo), RELU, residual=idn)   # conv3 + bn3 + add + relu
+                a_next = None
             if keep:
                 saved.append((cur, a, b, out))
             cur, hh, ww = out, ho, wo
@@ -257,11 +308,14 @@ class ResNetFn(Function):
         gf = (gfeat.float() * (1.0 / (hh * ww))).contiguous()
         _lib.call("wu_sumpool_bwd", gf.data_ptr(), g.data_ptr(), nhwc_ld(g), n, hh, ww, c, code, stream_ptr())
         g = K.act_gate(g, last, RELU, out=g)                        # gradient wrt the last block's pre-ReLU sum
-        for bi, (blk, (xin, a, b, out)) in enumerate(zip(reversed(plan["blocks"]), reversed(saved))):
+        blocks = plan["blocks"]
+        gb_pre = None                       # conv3^T of the block being entered, when the following block's chained launch produced it
+        for bi in range(len(blocks) - 1, -1, -1):
+            blk, (xin, a, b, out) = blocks[bi], saved[bi]
             s, planes = blk["stride"], blk["planes"]
             g_out = g
             # g: gradient of this block's output, already gated by its final ReLU
-            gb = conv1x1(g, blk["c3"]["wt"], None, new(planes, b.shape[2], b.shape[3]), NONE, egate=b, egate_act=RELU)
+            gb = gb_pre if gb_pre is not None else conv1x1(g, blk["c3"]["wt"], None, new(planes, b.shape[2], b.shape[3]), NONE, egate=b, egate_act=RELU)
             ga = new(planes, a.shape[2], a.shape[3])
             if s == 1:
                 K.conv3x3(gb, blk["c2"]["wd"], None, ga, egate=a, egate_act=RELU)
@@ -273,10 +327,18 @@ class ResNetFn(Function):
                 skip = g
             # gradient wrt the block input = conv1 path + identity path; gated by the ReLU that produced the input (every block
             # input is a ReLU output; for the first block it is max-pool(ReLU(stem)): x > 0 there implies the routed stem element > 0)
-            g = conv1x1(ga, blk["c1"]["wt"], None, new(xin.shape[1], xin.shape[2], xin.shape[3]), NONE, residual=skip,
-                        egate=xin, egate_act=RELU)
+            prev = blocks[bi - 1] if bi > 0 else None
+            g = new(xin.shape[1], xin.shape[2], xin.shape[3])
+            if prev is not None and "wtp" in blk["c1"] and "wtp" in prev["c3"] and chain_supported(planes, xin.shape[1], prev["planes"], code):
+                # ... and conv3^T of the previous block (gated by the ReLU of its 3x3 conv's output) from the tile that is still on chip
+                pb = saved[bi - 1][2]
+                gb_pre = new(prev["planes"], pb.shape[2], pb.shape[3])
+                conv1x1_chain(ga, blk["c1"]["wtp"], None, skip, NONE, xin, RELU, g, prev["c3"]["wtp"], None, NONE, pb, RELU, gb_pre)
+            else:
+                conv1x1(ga, blk["c1"]["wt"], None, g, NONE, residual=skip, egate=xin, egate_act=RELU)
+                gb_pre = None
             if CAPTURE is not None:      # tracing hook (tests: block-by-block gradient checks with the upstream gradient held fixed)
-                CAPTURE.append({"block": len(saved) - 1 - bi, "stride": s, "xin": xin, "out": out, "g_out": g_out, "g_in": g})
+                CAPTURE.append({"block": bi, "stride": s, "xin": xin, "out": out, "g_out": g_out, "g_in": g})
         gstem = maxpool3s2_bwd(g, amax, stem, new(64, stem.shape[2], stem.shape[3]), gate_act=RELU)
         dx = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
         stem7x7_dgrad(gstem, plan["stem_w"], dx, code)
