@@ -30,7 +30,7 @@ GFLOP_FWD_BWD_256 = 254.4      # conv MAC*2, fwd + dgrad + wgrad, per 256x256 im
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = "r03_pmc.json"      # scratch/pmc_collect.py output for the current kernels (see roofline.traffic)
+PMC_FILE = "r04_pmc.json"      # scratch/pmc_collect.py output for the current kernels (see roofline.traffic)
 
 
 def parse():

@@ -37,8 +37,8 @@ B = 32
 
 
 def short(name):
-    for key in ("conv3x3_mfma_v2_kernel", "conv3x3_wgrad_v2_kernel", "wgrad_reduce_kernel", "adain_upcat_bwd_march_kernel", "adain_upcat_bwd_gather_kernel",
-                "adain_upcat_bwd_apply_kernel", "adain_upcat_fwd_kernel", "maxpool2_bwd_kernel", "conv1x1_tanh_bwd_kernel", "conv1x1_tanh_fwd_kernel",
+    for key in ("conv3x3_mfma_v2_kernel", "conv3x3_wgrad_v2_kernel", "wgrad_reduce_kernel", "adain_upcat_bwd_tile_kernel", "adain_upcat_bwd_apply_rows_kernel",
+                "adain_upcat_bwd_march_kernel", "adain_upcat_bwd_gather_kernel", "adain_upcat_bwd_apply_kernel", "adain_upcat_fwd_march_kernel", "adain_upcat_fwd_kernel", "maxpool2_bwd_kernel", "conv1x1_tanh_bwd_kernel", "conv1x1_tanh_fwd_kernel",
                 "conv3x3_c3_wgrad_mfma_kernel", "conv3x3_c3_fwd_mfma_kernel", "adain_stats_kernel", "adain_stats_final_kernel", "adain_style_fwd_kernel",
                 "adain_style_bwd_kernel", "thin_fold_kernel", "fold_partials_kernel", "pack_conv3x3_kernel", "multi_tensor_apply_kernel"):
         if key in name:

@@ -45,6 +45,8 @@ from wu.ddp import GradBucketReducer, broadcast_buffers, is_distributed, ready_o
 OVERLAP_D_WITH_ESTIMATOR = os.environ.get("WU_GAN_OVERLAP", "1") == "1"
 # update_discriminator: the discriminator's real-batch and fake-batch passes on two streams (A/B switch)
 OVERLAP_D_PASSES = os.environ.get("WU_GAN_OVERLAP_D", "1") == "1"
+# ... also when the discriminator's gradients go through a bucketed reducer (multi-GPU); WU_GAN_OVERLAP_D_DDP=0: sequential passes then
+OVERLAP_D_WITH_REDUCER = os.environ.get("WU_GAN_OVERLAP_D_DDP", "1") == "1"
 # step(): the generator's encoder once per iteration instead of twice (A/B switch)
 SHARE_ENCODER = os.environ.get("WU_GAN_SHARE_ENCODER", "1") == "1"
 # with a pass on the second stream, a parameter's AccumulateGrad node (created on the main stream) receives gradients produced on the
@@ -131,14 +133,16 @@ class WeatherTransferStep:
                 pred_labels = c_d                                                        # :294-295
             elif pred_labels is None:
                 pred_labels = self.estimator(images)                                     # :297
-        if OVERLAP_D_PASSES and self.d_red is None and images.is_cuda and disc_batched_sn():
+        if OVERLAP_D_PASSES and (self.d_red is None or OVERLAP_D_WITH_REDUCER) and images.is_cuda and disc_batched_sn():
             # The pass over the REAL batch needs the images and their labels only: it runs on the second stream, beside the generator's
             # no-grad forward and then beside the pass over the FAKE batch (the kernels of one pass at B = 32 leave much of the chip
             # idle; the two backward chains overlap the same way: autograd replays a node on the stream of its forward).  The only
             # coupling between the passes is the power-iteration state -- the fake pass iterates the u / v the real pass's iteration
             # left (disc.py: one iteration per forward, real first: t_cls_train.py:299,303) -- so the fake pass waits for the real
-            # pass's batched normalisation (SNDisc.sn_done), not for its convs.  Without a gradient reducer only: its hooks assume one
-            # producing stream.
+            # pass's batched normalisation (SNDisc.sn_done), not for its convs.  With a gradient reducer too (round 4): a parameter's
+            # two contributions (one per pass, produced on two streams) are summed by autograd's input buffer on the parameter's own
+            # stream BEFORE its post-accumulate hook fires, so the bucket's all-reduce is ordered behind both producers
+            # (tests/test_gpu_round3.py::test_two_process_data_parallel_real_kernels runs this schedule on two ranks).
             main, side = torch.cuda.current_stream(images.device), self._d_stream(images.device)
             side.wait_stream(main)                           # the labels' producer, last step's optimizer
             with torch.cuda.stream(side):
