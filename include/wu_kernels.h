@@ -50,12 +50,14 @@ int wu_cu_count(void);
  *   1: persistent tile loop on/off      2: LDS-DMA wgrad (0 off, 1 = 8 waves (default), 2 = 4 waves)      3: unused
  *   4: wgrad DMA issue spread over K-steps (default 1)   5: first conv (0 matrix cores in bf16 (default), 1 rows kernel, 2 VALU kernel)
  *   6: static priority for the younger wave half (default 1)   7: grid-strided tile assignment (default 1)
- *   8: AdaIN-upsample backward (0 = 16-tap gather, 1 = marching, columns per thread by size (default), 2 / 3 = one / two columns)
+ *   8: AdaIN-upsample backward (0 = 16-tap gather, 1 = default: bf16 with keep bits streams through an LDS ring, everything else marches
+ *      with the columns per thread chosen by size; 2 / 3 = marching with one / two columns, 5 = marching also where the ring kernel would run)
  *   9: marching AdaIN-upsample forward (default 1)
  *   10: persistent-grid size override in compute units (0 = the device's count; experiments on CU-masked streams)
  *   11: Cin = 64 / one-cout-tile convs keep both weight chunks resident in LDS across a workgroup's tiles (default 1)
  *   12: pointwise-GEMM pixel tile (0 = 64 rows (default), 1 = 256 rows, 2 = 128 rows)
- *   13: image-layout 3 -> 3 conv (SNDisc's first layer): 1 = LDS-tiled kernels (default), 0 = one thread per pixel */
+ *   13: image-layout 3 -> 3 conv (SNDisc's first layer): 1 = LDS-tiled kernels (default), 0 = one thread per pixel
+ *   14: stride-2 data gradient: 1 = four parity-class sparse-tap convs in one launch (default), 0 = zero-stuffed dY + stride-1 conv */
 int wu_set_option(int key, int value);
 /* Diagnostic: device buffer of 256*8*8 uint64 receiving per-wave phase cycle sums of the persistent conv / wgrad kernels
  * (DMA wait, compute, whole-kernel s_memtime and s_memrealtime deltas -> in-kernel clock, barrier, epilogue, tiles, chunks);

@@ -66,32 +66,39 @@ def main():
               ("down3.0", 128, 256, S // 4, "bits"), ("down3.2", 256, 256, S // 4, "pool"), ("down4.0", 256, 512, S // 8, "bits"),
               ("down4.2", 512, 512, S // 8, "plain"), ("up3.0", 768, 256, S // 4, "bits"), ("up3.2", 256, 256, S // 4, "plain"),
               ("up2.0", 384, 128, S // 2, "bits"), ("up2.2", 128, 128, S // 2, "plain"), ("up1.0", 192, 64, S, "bits"), ("up1.2", 64, 64, S, "plain")]
-    tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
-    for name, ci, co, s, kind in layers:
-        x, gy = act(ci, s, relu=kind != "bits" or name.startswith("down")), act(co, s)
-        w = (torch.rand((co, ci, 3, 3), device=dev) * 2 - 1) * 0.05
-        wf, wd = K.pack_conv3x3(w, 1)
-        bias = torch.zeros(co, device=dev)
-        y, dx = empty_nhwc(B, co, s, s, bf, dev), empty_nhwc(B, ci, s, s, bf, dev)
-        fl = 2.0 * B * s * s * 9 * ci * co
-        if kind == "pool":
-            pl = empty_nhwc(B, co, s // 2, s // 2, bf, dev)
-            t_f = run(lambda: K.conv3x3_relu_pool(x, wf, bias, y, pl))
-        elif kind == "bits":
-            gbo = K.gate_bits_alloc(y)
-            t_f = run(lambda: K.conv3x3_bits(x, wf, bias, y, 1, gate_bits_out=gbo))
-        else:
-            t_f = run(lambda: K.conv3x3(x, wf, bias, y, 1, 1))
-        if kind == "bits":
-            t_d = run(lambda: K.conv3x3(gy, wd, None, dx))
-        else:
-            gbi = torch.randint(-2**31, 2**31 - 1, (K.gate_bits_alloc(dx).numel(),), dtype=torch.int32, device=dev)
-            t_d = run(lambda: K.conv3x3_bits(gy, wd, None, dx, egate_bits=gbi))
-        dw, db = torch.empty_like(w), torch.empty(co, device=dev)
-        t_w = run(lambda: K.conv3x3_wgrad(x, gy, dw, db))
-        tot["fwd"] += t_f; tot["dgrad"] += t_d; tot["wgrad"] += t_w
-        rows_conv.append((name, f"{ci}->{co} @{s}", fl / 1e9, t_f, fl / t_f / 1e6, t_d, fl / t_d / 1e6, t_w, fl / t_w / 1e6))
-        del x, gy, y, dx
+    # TWO passes over the list, the second one reported: whatever the table measures first reads 10-25 % slow (r04: down1.2 forward 205 us
+    # as the first row against 151-163 us for the same kernel on the same inputs later in the process, warm-up launches of another shape
+    # notwithstanding -- profiles/r04_down12_probe.txt); the first pass's numbers are printed to the log for comparison
+    for rep in range(2):
+      rows_conv.clear()
+      tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+      for name, ci, co, s, kind in layers:
+          x, gy = act(ci, s, relu=kind != "bits" or name.startswith("down")), act(co, s)
+          w = (torch.rand((co, ci, 3, 3), device=dev) * 2 - 1) * 0.05
+          wf, wd = K.pack_conv3x3(w, 1)
+          bias = torch.zeros(co, device=dev)
+          y, dx = empty_nhwc(B, co, s, s, bf, dev), empty_nhwc(B, ci, s, s, bf, dev)
+          fl = 2.0 * B * s * s * 9 * ci * co
+          if kind == "pool":
+              pl = empty_nhwc(B, co, s // 2, s // 2, bf, dev)
+              t_f = run(lambda: K.conv3x3_relu_pool(x, wf, bias, y, pl))
+          elif kind == "bits":
+              gbo = K.gate_bits_alloc(y)
+              t_f = run(lambda: K.conv3x3_bits(x, wf, bias, y, 1, gate_bits_out=gbo))
+          else:
+              t_f = run(lambda: K.conv3x3(x, wf, bias, y, 1, 1))
+          if kind == "bits":
+              t_d = run(lambda: K.conv3x3(gy, wd, None, dx))
+          else:
+              gbi = torch.randint(-2**31, 2**31 - 1, (K.gate_bits_alloc(dx).numel(),), dtype=torch.int32, device=dev)
+              t_d = run(lambda: K.conv3x3_bits(gy, wd, None, dx, egate_bits=gbi))
+          dw, db = torch.empty_like(w), torch.empty(co, device=dev)
+          t_w = run(lambda: K.conv3x3_wgrad(x, gy, dw, db))
+          tot["fwd"] += t_f; tot["dgrad"] += t_d; tot["wgrad"] += t_w
+          rows_conv.append((name, f"{ci}->{co} @{s}", fl / 1e9, t_f, fl / t_f / 1e6, t_d, fl / t_d / 1e6, t_w, fl / t_w / 1e6))
+          del x, gy, y, dx
+
+      print(f"pass {rep}: fwd {tot['fwd']:.0f} dgrad {tot['dgrad']:.0f} wgrad {tot['wgrad']:.0f} us; first row {rows_conv[0][3]:.1f} / {rows_conv[0][5]:.1f} / {rows_conv[0][7]:.1f}", flush=True)
 
     # ---- glue ----
     def g(name, t, nbytes):
