@@ -147,6 +147,15 @@ int wu_conv3x3_fwd_bits(const void* x, int ldx, const void* w_packed, const floa
  * conv is followed by wu_maxpool2_fwd.  Same argument rules as wu_conv3x3_fwd (stride 1); H and W even. */
 int wu_conv3x3_relu_pool_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                              void* pool, int ldpool, int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+/* The same with TWO bits per element of y from the epilogue (round 4; LDS-DMA path: ask wu_conv3x3_gate_bits_supported): the ReLU gate
+ * (gate-bit layout, above) and, in the same layout, "this element is the FIRST maximum of its 2x2 window" (scan order (0,0), (0,1), (1,0),
+ * (1,1): torch.nn.MaxPool2d's rule).  wu_maxpool2_bwd_bits computes MaxPool2d's backward fused with the skip-gradient sum and the ReLU
+ * gate (cunet.py:46,49,52 in backward) from those bits instead of the activation tensor. */
+int wu_conv3x3_relu_pool_bits_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                                  void* pool, int ldpool, void* gate_bits_out, void* sel_bits_out,
+                                  int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+int wu_maxpool2_bwd_bits(const unsigned* gate_bits, const unsigned* sel_bits, const void* dy, int lddy, const void* dskip, int lddskip,
+                         void* dx, int lddx, int N, int H, int W, int C, int dtype, void* stream);
 
 /* Weight + bias gradient of the conv above: dw_oihw[Cout][Cin][3][3] (+)= sum_pixels dy (x) x,
  * dbias[Cout] (+)= sum dy, with dy gated by act'(y) when `y` != NULL.  `workspace` must hold

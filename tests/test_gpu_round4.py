@@ -309,3 +309,61 @@ def test_estimator_chained_pointwise_is_bitwise_the_unchained_network():
     for a, b, name in zip(res[False], res[True], ("outputs", "input gradient", "no-grad outputs")):
         assert torch.isfinite(a).all() and a.abs().max().item() > 0
         assert torch.equal(a, b), f"{name}: chained != unchained (max {(a - b).abs().max().item():.3e})"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# gate + arg-max bits from the fused pool epilogue, max-pool backward from bits (conv3x3_mfma_v2 GATED = 4, glue.hip; cunet.py:46,49,52)
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 64), (1, 128, 128, 48, 96), (2, 256, 256, 16, 32), (1, 64, 64, 34, 38)])
+@pytest.mark.parametrize("sliced", [False, True])
+def test_pool_epilogue_bits_and_maxpool_backward_from_bits(shape, sliced):
+    """The forward + pool + bits conv instance: y and the pooled tensor bit-identical to the plain fused-pool conv; the two bit planes equal
+    to (y > 0) and to torch's max_pool2d arg-max (first maximum in scan order, ties included: ReLU outputs are full of equal zeros); and the
+    bits-based backward bit-identical to the tensor-based one (with the skip gradient, incl. an output that is a channel slice of a
+    concat buffer, 8-wave and 4-wave conv instances, ragged tiles)."""
+    import torch.nn.functional as F
+    from wu import _lib, kernels as K
+    from wu.layout import as_nhwc, empty_nhwc
+    n, cin, cout, h, w = shape
+    dev, bf = _dev(), torch.bfloat16
+    x = as_nhwc(torch.relu(_rand((n, cin, h, w), 31)).to(dev), _lib.BF16)
+    wt = _rand((cout, cin, 3, 3), 32, -0.1, 0.1)
+    bias = _rand((cout,), 33, -0.3, 0.1).to(dev)
+    wf, _ = K.pack_conv3x3(wt.to(dev), _lib.BF16)
+    extra = 64 if sliced else 0
+    buf_a, buf_b = empty_nhwc(n, extra + cout, h, w, bf, dev), empty_nhwc(n, extra + cout, h, w, bf, dev)
+    ya, yb = buf_a[:, extra:], buf_b[:, extra:]
+    if not K.gate_bits_supported(x, ya):
+        pytest.skip("shape outside the LDS-DMA conv")
+    pa, pb = empty_nhwc(n, cout, h // 2, w // 2, bf, dev), empty_nhwc(n, cout, h // 2, w // 2, bf, dev)
+    gb, sb = K.gate_bits_alloc(ya), K.gate_bits_alloc(ya)
+    gb.fill_(0x55555555); sb.fill_(0x55555555)
+    K.conv3x3_relu_pool(x, wf, bias, ya, pa)
+    K.conv3x3_relu_pool_bits(x, wf, bias, yb, pb, gb, sb)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb) and torch.equal(pa, pb)
+    # decode the bit planes: word (pixel, ct, hf), bit 8k + i  <->  channel 64 ct + 16 k + 8 hf + i
+    def decode(bits):
+        wv = bits.view(n, h, w, cout // 64, 2).to(torch.int64) & 0xffffffff
+        out = torch.zeros((n, h, w, cout), dtype=torch.bool, device=dev)
+        for k in range(4):
+            for i in range(8):
+                b = ((wv >> (8 * k + i)) & 1).bool()                     # (n, h, w, ct, hf)
+                for hf in range(2):
+                    out[..., torch.arange(cout // 64, device=dev) * 64 + 16 * k + 8 * hf + i] = b[..., hf]
+        return out.permute(0, 3, 1, 2)
+    yf = ya.float()
+    assert torch.equal(decode(gb), yf > 0), "gate bits"
+    _, idx = F.max_pool2d(yf, 2, return_indices=True)                    # flat index into (h, w) of each window's first maximum
+    want_sel = torch.zeros((n, cout, h * w), dtype=torch.bool, device=dev)
+    want_sel.scatter_(2, idx.reshape(n, cout, -1), True)
+    assert torch.equal(decode(sb), want_sel.view(n, cout, h, w)), "arg-max bits"
+    # backward: bits vs tensor
+    gy = as_nhwc(_rand((n, cout, h // 2, w // 2), 34).to(dev), _lib.BF16)
+    gs = as_nhwc(_rand((n, cout, h, w), 35).to(dev), _lib.BF16)
+    for dskip in (gs, None):
+        d1, d2 = empty_nhwc(n, cout, h, w, bf, dev), empty_nhwc(n, cout, h, w, bf, dev)
+        K.maxpool2_bwd(ya, gy, d1, dskip=dskip, gate_act=K.ACT_RELU)
+        K.maxpool2_bwd_bits(gb, sb, gy, d2, dskip=dskip)
+        torch.cuda.synchronize()
+        assert torch.equal(d1, d2), f"max-pool backward from bits differs (skip gradient: {dskip is not None})"

@@ -464,3 +464,25 @@ extern "C" int wu_conv3x3_relu_pool_fwd(const void* x, int ldx, const void* w_pa
     if (rc) return rc;
     return wu_maxpool2_fwd(y, ldy, pool, ldpool, N, H, W, Cout, dtype, stream);
 }
+
+// ... and, from the same epilogue, TWO bits per element of y (round 4): the ReLU gate (y > 0) and "this element is its 2x2 window's first
+// maximum" -- both in the gate-bit word layout of wu_conv3x3_fwd_bits (wu_kernels.h).  wu_maxpool2_bwd_bits then routes the pooled gradient,
+// adds the skip gradient and applies the gate from 2 bits per element instead of re-reading y (470 MB per B = 32 step over the three
+// encoder levels).  LDS-DMA path only: ask wu_conv3x3_gate_bits_supported first.
+extern "C" int wu_conv3x3_relu_pool_bits_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                                             void* pool, int ldpool, void* gate_bits_out, void* sel_bits_out,
+                                             int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    WU_REQUIRE(N > 0 && H > 0 && W > 0 && x && y && w_packed && pool && gate_bits_out && sel_bits_out, "conv3x3_relu_pool_bits_fwd: bad args");
+    WU_REQUIRE(wu_conv3x3_gate_bits_supported(H, W, ldx, ldy, Cin, Cout, dtype), "conv3x3_relu_pool_bits_fwd: shape/dtype outside the LDS-DMA conv (ask wu_conv3x3_gate_bits_supported)");
+    WU_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv3x3_relu_pool_bits_fwd: H=%d W=%d must be even", H, W);
+    WU_REQUIRE(ldx >= Cin && ldy >= Cout && ldpool >= Cout && (ldx * 2) % 16 == 0 && (ldy * 2) % 16 == 0 && (ldpool * 2) % 16 == 0, "conv3x3_relu_pool_bits_fwd: bad ld");
+    WU_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)pool % 16) == 0 &&
+               ((uintptr_t)gate_bits_out % 4) == 0 && ((uintptr_t)sel_bits_out % 4) == 0, "conv3x3_relu_pool_bits_fwd: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    wu_prof_pre(WU_FAM_CONV_FWD, s);
+    const int rc = conv_v2_launch(x, ldx, w_packed, bias, y, ldy, nullptr, 0, 0, N, H, W, Cin, Cout, WU_ACT_RELU, s, pool, ldpool, gate_bits_out, nullptr, sel_bits_out);
+    WU_REQUIRE(rc == 0, "conv3x3_relu_pool_bits_fwd: grid too large");
+    wu_prof_post(WU_FAM_CONV_FWD, s, 2.0 * N * H * W * (double)Cout * 9.0 * Cin, ((double)N * H * W * (Cin + Cout) + 9.0 * Cin * Cout) * 2 + (double)N * H * W * Cout / 4.0);
+    WU_LAUNCH_CHECK("conv3x3_mfma_v2 (+pool +bits)");
+    return 0;
+}

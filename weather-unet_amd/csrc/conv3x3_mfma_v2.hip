@@ -46,6 +46,7 @@ struct V2Args {
     // y[pixel][64 ct + 16 k + 8 hf + i] > 0 -- exactly the 32 channels lane (pixel, hf) holds in the epilogue, so a gate is one
     // dword per lane and row instead of four 16-byte loads
     unsigned* gbits;             // optional output (forward, act == RELU)
+    unsigned* sbits;             // optional output (forward + pool, GATED == 4): bit set = this element is its 2x2 window's FIRST maximum
     const unsigned* egbits;      // optional input (data gradient): replaces egate / egate_act = RELU
     int ldx, ldy, ldegate, egate_act, ldpool;
     int N, H, W, Cin, Cout, act;
@@ -105,7 +106,8 @@ template <bool M16_, int RPW_> struct AccT { using type = f32x16_t[RPW_][2]; };
 template <int RPW_> struct AccT<true, RPW_> { using type = f32x4_t[RPW_][2][4]; };
 
 // GATED: 0 = forward; 1 / 2 = the data-gradient form (a gate in the epilogue, no bias) with the gate as a tensor / as bits;
-// 3 = forward (ReLU) that also writes the gate bits of its output -- separate instances so that
+// 3 = forward (ReLU) that also writes the gate bits of its output; 4 = forward (ReLU) + 2x2 max-pool that also writes, per element of
+// its output, the gate bit AND the pool's arg-max bit (round 4: the max-pool backward then reads 2 bits instead of the tensor) -- separate instances so that
 // the gate-tensor prefetch registers (32 / 64), the bias registers (32) and neither of them are allocated as each case needs
 template <int NW, int GATED>
 __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a) {
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
             WU_STAMP(t_wait);
             __syncthreads();     // ... and so have everyone else's; everyone is also done with the other buffer
             WU_STAMP(t_epi_b2);  // (diagnostic) chunk-top barrier time is folded into the 'barrier2' slot
-            if (last && (GATED == 0 || GATED == 3)) {      // requested in the LAST chunk: lands under its MFMAs, and its registers are free for `ov` before
+            if (last && (GATED == 0 || GATED == 3 || GATED == 4)) {      // requested in the LAST chunk: lands under its MFMAs, and its registers are free for `ov` before
                 const int ct_ = cur.ct;
                 if constexpr (M16) {
 #pragma unroll
@@ -543,9 +545,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                             *(uint2*)(scr + (mi * 32 + 16 * ph + l15) * SCR_PITCH + (16 * cb + 4 * q16) * 2) = o;
                         }
             }
-            unsigned gb[Q::RPW];
+            unsigned gb[Q::RPW], sb[Q::RPW];
 #pragma unroll
-            for (int i = 0; i < Q::RPW; ++i) gb[i] = 0u;
+            for (int i = 0; i < Q::RPW; ++i) gb[i] = sb[i] = 0u;
 #pragma unroll
             for (int mp = 0; mp < Q::RPW / 2; ++mp) {                // the wave's rows in vertical pairs (even, odd)
                 const int ohe = oh0 + Q::RPW * wave + 2 * mp, ow = ow0 + l31;
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                             }
                             ov[((mp * 2 + ni) * 2 + (g >> 1)) * 2 + r] = v;       // stored from inside the next tile's first chunk
                             vr[r] = v;
-                            if (GATED == 3 && ACT == WU_ACT_RELU)
+                            if ((GATED == 3 || GATED == 4) && ACT == WU_ACT_RELU)
                                 gb[2 * mp + r] |= nonzero_byte(v) << (8 * (2 * ni + (g >> 1)));
                         }
                         if (POOL) {
@@ -615,8 +617,34 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                                 const int Hp = a.H >> 1, Wp = a.W >> 1;
                                 *(uint4*)(a.pool + (((size_t)n * Hp + (ohe >> 1)) * Wp + (ow >> 1)) * a.ldpool + co0 + 8 * lh + 32 * ni + 8 * g) = m;
                             }
+                            if constexpr (GATED == 4) {
+                                // arg-max bits: element e of (row r, this lane's column) is the window's FIRST maximum in scan order (0,0), (0,1),
+                                // (1,0), (1,1) -- PyTorch's rule, what maxpool2_bwd_kernel re-derives from the tensor.  eq byte: bit e = (v == max).
+                                const uint4 x0 = make_uint4(vr[0].x ^ m.x, vr[0].y ^ m.y, vr[0].z ^ m.z, vr[0].w ^ m.w);
+                                const uint4 x1 = make_uint4(vr[1].x ^ m.x, vr[1].y ^ m.y, vr[1].z ^ m.z, vr[1].w ^ m.w);
+                                const uint32_t eq0 = ~nonzero_byte(x0) & 0xffu, eq1 = ~nonzero_byte(x1) & 0xffu;
+                                const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)(eq0 | (eq1 << 8)), 0xB1, 0xF, 0xF, true);   // the other column
+                                const uint32_t oddm = (l31 & 1) ? 0xffu : 0u;
+                                const uint32_t nb0 = nb & 0xffu, nb1 = (nb >> 8) & 0xffu;
+                                const uint32_t s0 = eq0 & ~(nb0 & oddm);                                   // (0,1) yields to (0,0)
+                                const uint32_t s1 = eq1 & ~eq0 & ~nb0 & ~(nb1 & oddm);                     // row 1 yields to row 0; (1,1) also to (1,0)
+                                sb[2 * mp] |= s0 << (8 * (2 * ni + (g >> 1)));
+                                sb[2 * mp + 1] |= s1 << (8 * (2 * ni + (g >> 1)));
+                            }
                         }
                     }
+            }
+            if constexpr (GATED == 4) {
+                // stored right here, like the pooled tensor above (a pool instance pays the immediate-store wait at the next chunk top anyway)
+#pragma unroll
+                for (int mi = 0; mi < Q::RPW; ++mi) {
+                    const int oh = oh0 + Q::RPW * wave + mi, ow = ow0 + l31;
+                    if (oh < a.H && ow < a.W) {
+                        const size_t wi = (((size_t)n * a.H + oh) * a.W + ow) * (2 * a.cout_tiles) + 2 * cur.ct + lh;
+                        a.gbits[wi] = gb[mi];
+                        a.sbits[wi] = sb[mi];
+                    }
+                }
             }
             if (GATED == 3 && ACT == WU_ACT_RELU) {       // parked like `ov`: issued from the next tile's first chunk
 #pragma unroll
@@ -629,7 +657,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         using A1 = std::integral_constant<int, WU_ACT_RELU>;
         using A2 = std::integral_constant<int, WU_ACT_LEAKY>;
         using NoPool = std::false_type;
-        if constexpr (GATED == 3) {        // forward + gate bits: ReLU, no pool (conv_v2_launch)
+        if constexpr (GATED == 4) {        // forward + ReLU + pool + gate / arg-max bits
+            epi_store(A1{}, A0{}, std::true_type{});
+        } else if constexpr (GATED == 3) { // forward + gate bits: ReLU, no pool (conv_v2_launch)
             epi_store(A1{}, A0{}, NoPool{});
         } else if constexpr (GATED == 2) { // ReLU gate from bits
             epi_store(A0{}, A0{}, NoPool{});
@@ -691,7 +721,7 @@ bool conv_v2_eligible(int H, int W, int ldx, int ldy, int Cin, int Cout, int str
 
 int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
                    const void* egate, int ldegate, int egate_act, int N, int H, int W, int Cin, int Cout, int act, hipStream_t s,
-                   void* pool, int ldpool, void* gate_bits_out, const void* egate_bits) {
+                   void* pool, int ldpool, void* gate_bits_out, const void* egate_bits, void* sel_bits_out) {
     V2Args a;
     a.pool = (bf16_t*)pool; a.ldpool = ldpool;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.egate = (const bf16_t*)egate;
@@ -710,7 +740,7 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     static thread_local bool attr_set = false;
     if (!attr_set) {
 #define WU_V2_ATTR(NW_, G_) (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<NW_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-        WU_V2_ATTR(8, 0); WU_V2_ATTR(4, 0); WU_V2_ATTR(8, 1); WU_V2_ATTR(4, 1); WU_V2_ATTR(8, 2); WU_V2_ATTR(4, 2); WU_V2_ATTR(8, 3); WU_V2_ATTR(4, 3);
+        WU_V2_ATTR(8, 0); WU_V2_ATTR(4, 0); WU_V2_ATTR(8, 1); WU_V2_ATTR(4, 1); WU_V2_ATTR(8, 2); WU_V2_ATTR(4, 2); WU_V2_ATTR(8, 3); WU_V2_ATTR(4, 3); WU_V2_ATTR(8, 4); WU_V2_ATTR(4, 4);
 #undef WU_V2_ATTR
         attr_set = true;
     }
@@ -721,12 +751,17 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     if (gated != 1) a.egate = nullptr;
     a.egbits = (const unsigned*)egate_bits;
     a.gbits = (gated == 0 && act == WU_ACT_RELU && !pool) ? (unsigned*)gate_bits_out : nullptr;
+    a.sbits = nullptr;
     if (a.gbits) gated = 3;
+    if (gated == 0 && act == WU_ACT_RELU && pool && gate_bits_out && sel_bits_out) {       // + pool + gate / arg-max bits
+        a.gbits = (unsigned*)gate_bits_out; a.sbits = (unsigned*)sel_bits_out;
+        gated = 4;
+    }
     const bool nw4 = mode == 2 || (mode == 1 && Cin >= 256);
     a.w_resident = (!nw4 && Cin == 64 && a.cout_tiles == 1 && g_wu_opt[WU_OPT_CONV_W_RESIDENT]) ? 1 : 0;
 #define WU_V2_GO(NW_, G_) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<NW_, G_>), dim3((int)grid), dim3(NW_ * 64), 2 * K::BUF, s, a)
-    if (nw4) { if (gated == 3) WU_V2_GO(4, 3); else if (gated == 2) WU_V2_GO(4, 2); else if (gated == 1) WU_V2_GO(4, 1); else WU_V2_GO(4, 0); }
-    else { if (gated == 3) WU_V2_GO(8, 3); else if (gated == 2) WU_V2_GO(8, 2); else if (gated == 1) WU_V2_GO(8, 1); else WU_V2_GO(8, 0); }
+    if (nw4) { if (gated == 4) WU_V2_GO(4, 4); else if (gated == 3) WU_V2_GO(4, 3); else if (gated == 2) WU_V2_GO(4, 2); else if (gated == 1) WU_V2_GO(4, 1); else WU_V2_GO(4, 0); }
+    else { if (gated == 4) WU_V2_GO(8, 4); else if (gated == 3) WU_V2_GO(8, 3); else if (gated == 2) WU_V2_GO(8, 2); else if (gated == 1) WU_V2_GO(8, 1); else WU_V2_GO(8, 0); }
 #undef WU_V2_GO
     return 0;
 }

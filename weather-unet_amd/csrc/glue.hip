@@ -144,6 +144,37 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int ldx, const T* _
     }
 }
 
+// The same backward from BITS (round 4): the forward conv's epilogue left, per element of x, the ReLU gate (x > 0) and "first maximum of
+// its 2x2 window" (wu_conv3x3_relu_pool_bits_fwd; word layout of the gate bits: uint32 [pixel][C/64][2], bit 8k + i of word (p, ct, hf) =
+// channel 64 ct + 16 k + 8 hf + i), so x itself -- 2 bytes per element -- is not read again.  One thread = one 16-byte chunk of one
+// full-resolution pixel: dx = gate ? dskip + (sel ? dy[window] : 0) : 0, the arithmetic and the one rounding of the kernel above.
+__global__ __launch_bounds__(256) void maxpool2_bwd_bits_kernel(const unsigned* __restrict__ gbits, const unsigned* __restrict__ sbits,
+                                                                const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ dskip, int lddskip,
+                                                                bf16_t* __restrict__ dx, int lddx, int N, int H, int W, int C) {
+    const int cpp = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const unsigned total = (unsigned)N * H * W * cpp;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int ch = (int)(i % cpp);
+        const unsigned pix = i / cpp;                                   // (n, h, w) linear
+        const int w_ = (int)(pix % W);
+        const unsigned t = pix / W;
+        const int h_ = (int)(t % H), n = (int)(t / H);
+        const int c0 = ch * 8;
+        const unsigned wi = pix * (unsigned)(C >> 5) + 2 * (c0 >> 6) + ((c0 >> 3) & 1);     // word (pixel, ct, hf); C/64 * 2 words per pixel
+        const int sh = 8 * ((c0 & 63) >> 4);
+        const unsigned gate = (gbits[wi] >> sh) & 0xffu, sel = (sbits[wi] >> sh) & 0xffu;
+        float g[8], o[8];
+        unpack16<bf16_t>(*(const uint4*)(dy + ((size_t)(n * Ho + (h_ >> 1)) * Wo + (w_ >> 1)) * lddy + c0), g);
+        if (dskip) unpack16<bf16_t>(*(const uint4*)(dskip + (size_t)pix * lddskip + c0), o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = (dskip ? o[e] : 0.f) + (((sel >> e) & 1u) ? g[e] : 0.f);
+            o[e] = ((gate >> e) & 1u) ? v : 0.f;
+        }
+        *(uint4*)(dx + (size_t)pix * lddx + c0) = pack16<bf16_t>(o);
+    }
+}
+
 // =================================================================================================
 // AdaIN statistics (utils.py:34-39): shifted sums per (n,c), finalised to {mean, rstd}
 // =================================================================================================
@@ -1303,6 +1334,19 @@ extern "C" int wu_maxpool2_bwd(const void* x, int ldx, const void* dy, int lddy,
         DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2_bwd_kernel<T, long long>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                                              (const T*)x, ldx, (const T*)dy, lddy, (const T*)dskip, lddskip, (T*)dx, lddx, N, H, W, C, gate_act));
     WU_LAUNCH_CHECK("maxpool2_bwd");
+    return 0;
+}
+
+extern "C" int wu_maxpool2_bwd_bits(const unsigned* gate_bits, const unsigned* sel_bits, const void* dy, int lddy, const void* dskip, int lddskip,
+                                    void* dx, int lddx, int N, int H, int W, int C, int dtype, void* stream) {
+    WU_REQUIRE(dtype == WU_BF16, "maxpool2_bwd_bits: bf16 only (the bits come from the LDS-DMA conv)");
+    WU_REQUIRE(N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C % 64 == 0 && gate_bits && sel_bits && dy && dx, "maxpool2_bwd_bits: bad args");
+    WU_REQUIRE(ok16(dy, lddy, 2) && ok16(dx, lddx, 2) && (!dskip || ok16(dskip, lddskip, 2)) && lddy >= C && lddx >= C, "maxpool2_bwd_bits: alignment");
+    const long long total = (long long)N * H * W * (C / 8);
+    WU_REQUIRE(total < (1ll << 32), "maxpool2_bwd_bits: too many items for 32-bit indices");
+    hipLaunchKernelGGL(maxpool2_bwd_bits_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, gate_bits, sel_bits,
+                       (const bf16_t*)dy, lddy, (const bf16_t*)dskip, lddskip, (bf16_t*)dx, lddx, N, H, W, C);
+    WU_LAUNCH_CHECK("maxpool2_bwd_bits");
     return 0;
 }
 

@@ -155,6 +155,26 @@ def conv3x3_c3_dgrad(gy, weight, dx_nchw, stride, code, dy_nchw=False, y=None, a
               dx_nchw.data_ptr(), n, h, w, cout, stride, 1 if accumulate else 0, code, stream_ptr())
 
 
+def conv3x3_relu_pool_bits(x, w_packed, bias, y, pool, gate_bits, sel_bits):
+    """conv + bias + ReLU -> y, its 2x2 max-pool -> pool, and per element of y the ReLU-gate bit and the pool's arg-max bit
+    (wu_conv3x3_relu_pool_bits_fwd; callers check gate_bits_supported(x, y) first)."""
+    n, cin, h, w = x.shape
+    cout = y.shape[1]
+    _lib.call("wu_conv3x3_relu_pool_bits_fwd", x.data_ptr(), nhwc_ld(x), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+              y.data_ptr(), nhwc_ld(y), pool.data_ptr(), nhwc_ld(pool), gate_bits.data_ptr(), sel_bits.data_ptr(),
+              n, h, w, cin, cout, dtype_code(x), stream_ptr())
+    return y, pool
+
+
+def maxpool2_bwd_bits(gate_bits, sel_bits, gy, dx, dskip=None):
+    """MaxPool2d(2) backward + skip-gradient sum + ReLU gate from the two bit planes the forward conv left (wu_maxpool2_bwd_bits)."""
+    n, c, h, w = dx.shape
+    sp, sld = _pl(dskip)
+    _lib.call("wu_maxpool2_bwd_bits", gate_bits.data_ptr(), sel_bits.data_ptr(), gy.data_ptr(), nhwc_ld(gy), sp, sld, dx.data_ptr(), nhwc_ld(dx),
+              n, h, w, c, dtype_code(dx), stream_ptr())
+    return dx
+
+
 def maxpool2(x, y):
     n, c, h, w = x.shape
     _lib.call("wu_maxpool2_fwd", x.data_ptr(), nhwc_ld(x), y.data_ptr(), nhwc_ld(y), n, h, w, c, dtype_code(x), stream_ptr())

@@ -26,6 +26,9 @@ RELU = K.ACT_RELU
 SIDE_STREAM_WGRAD = True
 # ReLU gates between a block's two convs travel as bits (1/16 of the tensor) where the LDS-DMA conv runs (A/B switch)
 GATE_BITS = True
+# the encoder blocks' second conv (conv + ReLU + fused 2x2 max-pool) also leaves the gate bit and the pool's arg-max bit of every output
+# element, and the fused max-pool backward reads those 2 bits instead of the skip tensor itself (round 4; A/B switch)
+POOL_BITS = os.environ.get("WU_POOL_BITS", "1") == "1"
 # where the FIRST conv's weight gradient (the last kernel of the backward chain) is launched: True = side stream (round 2), False =
 # main stream.  Round 3 trace: the side stream has no slack at the end of backward any more -- the last persistent weight gradient
 # (down1.2), its reducer and this kernel ran one after the other for 230 us after the main stream's last data gradient had finished;
@@ -240,11 +243,19 @@ class UNetFn(Function):
                 K.conv3x3_c3_bits(x, w_first, wb["dconv_down1"][1], a1, gbits["dconv_down1"], 1, code)
             else:
                 K.conv3x3_c3(x, w_first, wb["dconv_down1"][1], a1, 1, RELU, False, code)
-            p1 = K.conv3x3_relu_pool(a1, pk["dconv_down1.2"][0], wb["dconv_down1"][3], conv1, _new(n, 64, h // 2, w // 2, dt, dev))[1]
+            def pool_conv(name, xin, out, pooled):
+                """Second conv of encoder block `name`: conv + bias + ReLU into the concat slice `out`, its 2x2 max-pool, and (when a
+                backward will follow and the LDS-DMA conv runs) the gate / arg-max bits of `out` for the fused max-pool backward."""
+                if POOL_BITS and GATE_BITS and enc_bits and K.gate_bits_supported(xin, out):
+                    gbits[name + ".pool"] = (K.gate_bits_alloc(out), K.gate_bits_alloc(out))
+                    return K.conv3x3_relu_pool_bits(xin, pk[name + ".2"][0], wb[name][3], out, pooled, *gbits[name + ".pool"])[1]
+                return K.conv3x3_relu_pool(xin, pk[name + ".2"][0], wb[name][3], out, pooled)[1]
+
+            p1 = pool_conv("dconv_down1", a1, conv1, _new(n, 64, h // 2, w // 2, dt, dev))
             a2 = mid_conv("dconv_down2", p1, _new(n, 128, h // 2, w // 2, dt, dev), enc_bits)
-            p2 = K.conv3x3_relu_pool(a2, pk["dconv_down2.2"][0], wb["dconv_down2"][3], conv2, _new(n, 128, h // 4, w // 4, dt, dev))[1]
+            p2 = pool_conv("dconv_down2", a2, conv2, _new(n, 128, h // 4, w // 4, dt, dev))
             a3 = mid_conv("dconv_down3", p2, _new(n, 256, h // 4, w // 4, dt, dev), enc_bits)
-            p3 = K.conv3x3_relu_pool(a3, pk["dconv_down3.2"][0], wb["dconv_down3"][3], conv3, _new(n, 256, h // 8, w // 8, dt, dev))[1]
+            p3 = pool_conv("dconv_down3", a3, conv3, _new(n, 256, h // 8, w // 8, dt, dev))
             a4 = mid_conv("dconv_down4", p3, _new(n, 512, h // 8, w // 8, dt, dev), enc_bits)
             b4 = K.conv3x3(a4, pk["dconv_down4.2"][0], wb["dconv_down4"][3], _new(n, 512, h // 8, w // 8, dt, dev), 1, RELU)
             if enc_cache is not None:
@@ -358,15 +369,20 @@ class UNetFn(Function):
         g_b4 = _new(*b4.shape, dt, dev)
         dys3, dym3 = K.adain_upcat_bwd(g_cat3, b4, st3, ys3, g_b4, p_drop, seeds[0], mb3, x_gate_act=RELU)
         # bottleneck + encoder: max-pool backward fused with the skip-gradient sum and the ReLU gate
+        def pool_bwd(name, skip, g_pooled, g_skip):
+            """max_pool2d backward + the skip tensor's second gradient (its concat slice) + its ReLU gate, in one pass: from the two bit
+            planes the forward conv left, or from the skip tensor itself."""
+            out = _new(*skip.shape, dt, dev)
+            if name + ".pool" in gbits:
+                return K.maxpool2_bwd_bits(*gbits[name + ".pool"], g_pooled, out, dskip=g_skip)
+            return K.maxpool2_bwd(skip, g_pooled, out, dskip=g_skip, gate_act=RELU)
+
         g_p3 = block_bwd("dconv_down4", p3, a4, g_b4)
-        conv3 = cat3[:, 512:]
-        g_conv3 = K.maxpool2_bwd(conv3, g_p3, _new(*conv3.shape, dt, dev), dskip=g_cat3[:, 512:], gate_act=RELU)
+        g_conv3 = pool_bwd("dconv_down3", cat3[:, 512:], g_p3, g_cat3[:, 512:])
         g_p2 = block_bwd("dconv_down3", p2, a3, g_conv3)
-        conv2 = cat2[:, 256:]
-        g_conv2 = K.maxpool2_bwd(conv2, g_p2, _new(*conv2.shape, dt, dev), dskip=g_cat2[:, 256:], gate_act=RELU)
+        g_conv2 = pool_bwd("dconv_down2", cat2[:, 256:], g_p2, g_cat2[:, 256:])
         g_p1 = block_bwd("dconv_down2", p1, a2, g_conv2)
-        conv1 = cat1[:, 128:]
-        g_conv1 = K.maxpool2_bwd(conv1, g_p1, _new(*conv1.shape, dt, dev), dskip=g_cat1[:, 128:], gate_act=RELU)
+        g_conv1 = pool_bwd("dconv_down1", cat1[:, 128:], g_p1, g_cat1[:, 128:])
         g_a1 = block_bwd("dconv_down1", x, a1, g_conv1)
         dx = None
         if ctx.needs_input_grad[1]:
