@@ -81,7 +81,8 @@ def main():
           fl = 2.0 * B * s * s * 9 * ci * co
           if kind == "pool":
               pl = empty_nhwc(B, co, s // 2, s // 2, bf, dev)
-              t_f = run(lambda: K.conv3x3_relu_pool(x, wf, bias, y, pl))
+              gbp, sbp = K.gate_bits_alloc(y), K.gate_bits_alloc(y)          # round 4: + gate / arg-max bits, as the training step launches it
+              t_f = run(lambda: K.conv3x3_relu_pool_bits(x, wf, bias, y, pl, gbp, sbp))
           elif kind == "bits":
               gbo = K.gate_bits_alloc(y)
               t_f = run(lambda: K.conv3x3_bits(x, wf, bias, y, 1, gate_bits_out=gbo))
@@ -124,7 +125,11 @@ def main():
         gy = act(c, h // 2)
         dxx = empty_nhwc(B, c, h, h, bf, dev)
         t = B * h * h * c * 2
-        g(f"maxpool2_bwd C={c} @{h} (+skip sum, ReLU gate)", run(lambda: K.maxpool2_bwd(x, gy, dxx, gs, 1)), 3 * t + t // 4)
+        gbp, sbp = K.gate_bits_alloc(x), K.gate_bits_alloc(x)
+        gbp.random_(); sbp.random_()
+        g(f"maxpool2_bwd_bits C={c} @{h} (+skip sum, ReLU gate; 2 bits per element instead of the tensor)", run(lambda: K.maxpool2_bwd_bits(gbp, sbp, gy, dxx, gs)), 2 * t + t // 4 + t // 8)
+        tb = run(lambda: K.maxpool2_bwd(x, gy, dxx, gs, 1))
+        print(f"  (tensor-based maxpool2_bwd C={c} @{h}: {tb:.1f} us)", flush=True)
         del x, gs, gy, dxx
     xi = torch.rand((B, 3, S, S), device=dev) * 2 - 1
     w = torch.rand((64, 3, 3, 3), device=dev) - 0.5
@@ -146,7 +151,7 @@ def main():
     path = os.path.join(root, "gpurun_out", f"{tag}_layer_table.md")
     with open(path, "w") as fh:
         fh.write(f"# {tag}: per-layer kernel table, cUNet {S}x{S} bf16 B={B}, every kernel stand-alone (median of 7 x (4 back-to-back launches / 4), hipEvents)\n\n")
-        fh.write("MFMA convs (peak 2500 TFLOP/s dense bf16): forward = conv+bias+ReLU (+fused 2x2 max-pool on the encoder blocks' second conv); "
+        fh.write("MFMA convs (peak 2500 TFLOP/s dense bf16): forward = conv+bias+ReLU (+fused 2x2 max-pool and gate / arg-max bits on the encoder blocks' second conv); "
                  "dgrad = data gradient as the fused graph launches it (gate bits of the block's first-conv output in the epilogue for *.2, ungated for *.0); wgrad = weight+bias gradient incl. its split-K reducer.\n\n")
         fh.write("| layer | shape | GFLOP | fwd us | fwd TFLOP/s | dgrad us | dgrad TFLOP/s | wgrad us | wgrad TFLOP/s |\n|---|---|---|---|---|---|---|---|---|\n")
         for r in rows_conv:
