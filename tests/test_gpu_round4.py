@@ -367,3 +367,49 @@ def test_pool_epilogue_bits_and_maxpool_backward_from_bits(shape, sliced):
         K.maxpool2_bwd_bits(gb, sb, gy, d2, dskip=dskip)
         torch.cuda.synchronize()
         assert torch.equal(d1, d2), f"max-pool backward from bits differs (skip gradient: {dskip is not None})"
+
+
+# (N, Cin, Cout, H, W): the estimator's stride-1 pointwise shapes at a small batch, a ragged row count, a single K step and a single tile
+PW3_SHAPES = [(2, 256, 1024, 16, 16), (2, 1024, 256, 16, 16), (3, 128, 512, 10, 10), (1, 512, 2048, 8, 8), (1, 2048, 512, 8, 8),
+              (2, 64, 256, 24, 20), (2, 512, 128, 9, 7), (1, 192, 128, 5, 5)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [2, 3, 4, 8 + 2, 8 + 3, 8 + 4])
+@pytest.mark.parametrize("shape", PW3_SHAPES)
+def test_pointwise_persistent_dma_kernel_is_bit_identical(shape, depth):
+    """conv1x1_pw3_kernel (round 4: 128 x 128 tiles, LDS-DMA ring of `depth & 7` stages, four or -- bit 3 -- eight waves, persistent workgroups, counted waits) against
+    conv1x1_mfma_kernel on the same operands, bitwise: plain; bias + residual + ReLU (the forward of a Bottleneck's conv3); gate only (data
+    gradient of conv3); residual + gate (data gradient of conv1 plus the identity path).  Outputs and residuals are channel slices of wider
+    buffers (ld > C), the grid is held at 5 workgroups so that every workgroup walks several tiles and the ring wraps across tile borders."""
+    from wu import _lib, resnet as RN
+    from wu.layout import as_nhwc, empty_nhwc
+    dev = _dev()
+    bf = torch.bfloat16
+    n, cin, cout, h, w = shape
+    x = as_nhwc(_rand((n, cin, h, w), 41).to(dev), _lib.BF16)
+    wt = _rand((cout, cin), 42, -0.1, 0.1).to(dev).to(bf).contiguous()
+    b = _rand((cout,), 43).to(dev)
+    res_buf = as_nhwc(_rand((n, cout + 64, h, w), 44).to(dev), _lib.BF16)
+    gate_buf = as_nhwc(_rand((n, cout + 128, h, w), 45).to(dev), _lib.BF16)
+    res, gate = res_buf[:, 64:], gate_buf[:, :cout]
+    OPT_PW3, OPT_GRID = 15, 10
+    cases = [dict(), dict(act=1, residual=res), dict(egate=gate, egate_act=1), dict(residual=res, egate=gate, egate_act=1), dict(act=1)]
+    try:
+        for ci, kw in enumerate(cases):
+            bias = None if ci in (2, 3) else b
+            outs = []
+            for opt, cus in ((0, 0), (depth, 0), (depth, 5)):
+                _lib.call("wu_set_option", OPT_PW3, opt)
+                _lib.call("wu_set_option", OPT_GRID, cus)
+                ybuf = empty_nhwc(n, cout + 64, h, w, bf, dev)
+                ybuf.fill_(7.0)
+                RN.conv1x1(x, wt, bias, ybuf[:, :cout], **kw)
+                torch.cuda.synchronize()
+                outs.append(ybuf)
+            assert torch.equal(outs[0], outs[1]), f"case {ci}: persistent kernel differs (or wrote outside its channels)"
+            assert torch.equal(outs[0], outs[2]), f"case {ci}: persistent kernel on 5 workgroups differs"
+            assert bool((outs[0][:, cout:] == 7.0).all())
+    finally:
+        _lib.call("wu_set_option", OPT_PW3, 2 + 8 + (128 << 4))        # the library's default (wu_prof.hip)
+        _lib.call("wu_set_option", OPT_GRID, 0)

@@ -10,6 +10,7 @@
 //   * maxpool3s2_*          the 3x3 stride-2 max-pool with stored arg-max (windows overlap: backward is a gather over the
 //                           <= 4 windows that contain a pixel).
 // The 3x3 convs of the blocks run on the conv3x3 kernels of this library (conv3x3_mfma_v2.hip / conv3x3_mfma.hip).
+#include <algorithm>
 #include <type_traits>
 
 #include "wu_common.h"
@@ -320,6 +321,273 @@ __global__ __launch_bounds__(256, TM == 256 ? 2 : (TM == 128 ? 3 : 4)) void conv
                     }
             }
     }
+}
+
+// =================================================================================================
+// Persistent LDS-DMA form of the pointwise GEMM (round 4; bf16, unit strides, Cout % 128 == 0): conv1x1_pw3_kernel
+// =================================================================================================
+// Measured on the estimator's shapes (scratch/pw_scaling.py, scratch/pw_vs_blas.py, launches timed inside a captured graph): the 64 x 64
+// tiles above move 1 byte from L2 per 32 flops -- the 64 B/clk L2 -> CU port alone caps them at half the matrix rate, the LDS fragment
+// traffic (two 1-KiB fragments per MFMA) at the same half -- and every workgroup is a chain of exposed round trips (first loads, K steps
+// two ahead, residual, store).  This form: 128 pixels x 128 couts per workgroup (four waves, 64 x 64 each: one fragment per MFMA, 1 byte
+// per 64 flops), operands by LDS-DMA through buffer descriptors into a ring of D 32-KiB stages (rows past the end of the GEMM are lanes
+// out of the descriptor's range: zeros), PERSISTENT workgroups whose prefetch runs across tile boundaries, and every vector-memory
+// operation of the loop (DMA pieces, residual / gate loads, output stores) issued from inline asm so that the waits are COUNTED by the
+// kernel (s_waitcnt vmcnt(N), N = operations younger than the stage about to be read: vmcnt retires in issue order) -- the compiler
+// never sees an outstanding load it would drain the ring for.  Same MFMA operand mapping, K order and epilogue arithmetic as
+// conv1x1_mfma_kernel: bit-identical results (tests/test_gpu_round4.py).
+namespace pw3 {
+constexpr int TM = 128, TN = 128;
+constexpr int kStage = (TM + TN) * kKB;          // 32 KiB: activation rows, then weight rows
+constexpr int kMaxCout = 2048;                   // bias image in LDS
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+struct Args {
+    const bf16_t* x; const bf16_t* w; const float* bias; const bf16_t* res; const bf16_t* egate; bf16_t* y;
+    int ldx, ldres, ldegate, ldy;
+    int M, Cin, Cout, act, egate_act;
+    int n_ct, items;            // cout tiles; pixel tiles x cout tiles
+};
+
+template <int OFF> __device__ __forceinline__ u32x4_t ld16(unsigned voff, wu_rsrc_t rs, unsigned soff) {
+    u32x4_t v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF> __device__ __forceinline__ void st16(u32x4_t v, unsigned voff, wu_rsrc_t rs, unsigned soff) {
+    // s_nop: the data registers of a 128-bit store may not be rewritten in the next cycle (the hazard recogniser does not see into asm)
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
+}
+// at most n (a multiple of 4, wave-uniform) vector-memory operations still in flight; anything above 60 waits for 60 (waiting for more is safe)
+__device__ __forceinline__ void vm_wait(int n) {
+    switch (n >> 2) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
+    }
+}
+}  // namespace pw3
+
+// NW waves: 4 (2 x 2, 64 pixels x 64 couts each) or 8 (4 x 2, 32 pixels x 64 couts each: two waves per SIMD with ONE workgroup per CU, so
+// that the whole LDS can be ring)
+template <int NW, int D, bool HAS_RES, bool HAS_GATE>
+__global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(const pw3::Args a) {
+    using namespace pw3;
+    constexpr int WM = NW == 8 ? 4 : 2, WN = NW / WM, MI = TM / (32 * WM), NI = TN / (32 * WN);
+    static_assert(NI == 2, "the epilogue's instruction offsets assume two 32-cout blocks per wave");
+    constexpr int PA = 16 / NW;          // 1-KiB pieces of each operand per wave and K step
+    constexpr int PD = 2 * PA;           // DMA operations per wave and K step
+    constexpr int PS = MI * NI * 2;      // output stores (residual loads, gate loads) per wave and tile
+    constexpr int NT = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bias_lds = (float*)(smem + D * kStage);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int G = (int)gridDim.x;
+    const int wg = xcd_remap(blockIdx.x, G);
+    const int nk = a.Cin / 64;
+
+    for (int i = tid; i < a.Cout; i += NT) bias_lds[i] = a.bias ? a.bias[i] : 0.f;
+    __syncthreads();
+
+    // ---- descriptors and tile-invariant per-lane byte offsets ----
+    const wu_rsrc_t rsA = wu_make_rsrc(a.x, (unsigned)((((size_t)a.M - 1) * a.ldx + a.Cin) * 2));
+    const wu_rsrc_t rsW = wu_make_rsrc(a.w, (unsigned)((size_t)a.Cout * a.Cin * 2));
+    const wu_rsrc_t rsY = wu_make_rsrc(a.y, (unsigned)((((size_t)a.M - 1) * a.ldy + a.Cout) * 2));
+    const wu_rsrc_t rsR = wu_make_rsrc(HAS_RES ? a.res : a.y, HAS_RES ? (unsigned)((((size_t)a.M - 1) * a.ldres + a.Cout) * 2) : 0u);
+    const wu_rsrc_t rsE = wu_make_rsrc(HAS_GATE ? a.egate : a.y, HAS_GATE ? (unsigned)((((size_t)a.M - 1) * a.ldegate + a.Cout) * 2) : 0u);
+    unsigned voA[PA], voW[PA];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int row = 8 * (wave + NW * j) + (lane >> 3);                 // piece wave + NW j holds rows 8 p .. 8 p + 7, lane l lands at + 16 l
+        const int sl = (lane & 7) ^ ((row >> 1) & 7);                      // the swizzle of pw_off, applied to the SOURCE slot
+        voA[j] = (unsigned)(row * a.ldx * 2 + sl * 16);
+        voW[j] = (unsigned)(row * a.Cin * 2 + sl * 16);
+    }
+    // epilogue: pixel rows 32 MI wm + 32 mi + l31, channels 64 wn + 32 ni + 16 gp + 8 lh (+ 8) -- (ni, gp) travel in the instruction offset
+    unsigned voY[MI], voR[MI], voE[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int r = 32 * MI * wm + 32 * mi + l31, c = 64 * wn + 8 * lh;
+        voY[mi] = (unsigned)((r * a.ldy + c) * 2);
+        voR[mi] = (unsigned)((r * a.ldres + c) * 2);
+        voE[mi] = (unsigned)((r * a.ldegate + c) * 2);
+    }
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    // ---- the two cursors over this workgroup's items (wg, wg + G, ...; cout tile fastest), carried digit by digit ----
+    const int dct = G % a.n_ct, dpt = G / a.n_ct;
+    int f_item = wg, f_ct = wg % a.n_ct, f_pt = wg / a.n_ct, f_k = 0;
+    bool f_alive = f_item < a.items;
+    auto fetch = [&](int stage) __attribute__((always_inline)) {
+        const unsigned kill = f_alive ? 0u : kWuOOB;
+        const unsigned soA = (unsigned)((f_pt * TM * a.ldx + f_k * 64) * 2) | kill;
+        const unsigned soW = (unsigned)((f_ct * TN * a.Cin + f_k * 64) * 2) | kill;
+        const unsigned lds = smem_base + stage * kStage + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) wu_dma16b(voA[j], rsA, soA, __builtin_amdgcn_readfirstlane(lds + j * NW * 1024));
+#pragma unroll
+        for (int j = 0; j < PA; ++j) wu_dma16b(voW[j], rsW, soW, __builtin_amdgcn_readfirstlane(lds + TM * kKB + j * NW * 1024));
+        if (f_alive && ++f_k == nk) {
+            f_k = 0; f_item += G;
+            f_ct += dct; const int cy = f_ct >= a.n_ct ? 1 : 0; f_ct -= cy * a.n_ct; f_pt += dpt + cy;
+            f_alive = f_item < a.items;
+        }
+    };
+
+    int st_f = 0, st_c = 0;
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) { fetch(st_f); st_f = st_f + 1 == D ? 0 : st_f + 1; }
+
+    // operations issued in the last D - 1 steps besides the PD DMA pieces: [j] = step s - 1 - j; pre = before that step's DMA (residual / gate
+    // loads), post = after it (output stores)
+    int h_pre[D - 1], h_post[D - 1];
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) h_pre[j] = h_post[j] = 0;
+    constexpr int NRG = PS * ((HAS_RES ? 1 : 0) + (HAS_GATE ? 1 : 0));
+    const bool relu = a.act == WU_ACT_RELU;
+
+    int c_ct = wg % a.n_ct, c_pt = wg / a.n_ct;
+    for (int c_item = wg; c_item < a.items; c_item += G) {
+        const int m0 = c_pt * TM, co0 = c_ct * TN;
+        f32x16_t acc[MI][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+        u32x4_t rq[MI][4], eq[MI][4];
+        for (int k = 0; k < nk; ++k) {
+            // the stage about to be read has landed: everything younger than its PD pieces may stay in flight
+            int n = (D - 2) * PD + h_post[D - 2];
+#pragma unroll
+            for (int j = 0; j < D - 2; ++j) n += h_pre[j] + h_post[j];
+            vm_wait(n);
+            __syncthreads();                 // ... for every wave; and every wave has left the stage the DMA below refills
+            int pre = 0;
+            if (NRG != 0 && k == 0) {        // this tile's residual / gate rows: in flight under its whole K loop
+                const unsigned soR = (unsigned)((m0 * a.ldres + co0) * 2), soE = (unsigned)((m0 * a.ldegate + co0) * 2);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    if constexpr (HAS_RES) {
+                        rq[mi][0] = ld16<0>(voR[mi], rsR, soR); rq[mi][1] = ld16<32>(voR[mi], rsR, soR);
+                        rq[mi][2] = ld16<64>(voR[mi], rsR, soR); rq[mi][3] = ld16<96>(voR[mi], rsR, soR);
+                    }
+                    if constexpr (HAS_GATE) {
+                        eq[mi][0] = ld16<0>(voE[mi], rsE, soE); eq[mi][1] = ld16<32>(voE[mi], rsE, soE);
+                        eq[mi][2] = ld16<64>(voE[mi], rsE, soE); eq[mi][3] = ld16<96>(voE[mi], rsE, soE);
+                    }
+                }
+                pre = NRG;
+            }
+            fetch(st_f); st_f = st_f + 1 == D ? 0 : st_f + 1;
+            {
+                // fragments of k-step ks + 1 are requested before the MFMAs of ks (two register sets): the LDS round trip of a step's
+                // first fragments is the only one a wave waits out
+                const char* a_lds = smem + st_c * kStage;
+                const char* w_lds = a_lds + TM * kKB;
+                uint4 af[2][MI], bf[2][NI];
+                auto frags = [&](int set, int ks) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) af[set][mi] = *(const uint4*)(a_lds + pw_off(32 * MI * wm + 32 * mi + l31, 2 * ks + lh));
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) bf[set][ni] = *(const uint4*)(w_lds + pw_off(64 * wn + 32 * ni + l31, 2 * ks + lh));
+                };
+                frags(0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks < 3) frags((ks + 1) & 1, ks + 1);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) PwMma<bf16_t>::run(acc[mi][ni], bf[ks & 1][ni], af[ks & 1][mi]);      // D^T = W * X^T
+                }
+            }
+            st_c = st_c + 1 == D ? 0 : st_c + 1;
+#pragma unroll
+            for (int j = D - 2; j > 0; --j) { h_pre[j] = h_pre[j - 1]; h_post[j] = h_post[j - 1]; }
+            h_pre[0] = pre; h_post[0] = 0;
+        }
+        // ---- epilogue: conv1x1_mfma_kernel's fast path (bias, + residual, activation, gate; one rounding), 16-byte stores ----
+        if (NRG != 0) {
+            if (nk < D) vm_wait(PD * nk);    // short K: the loads are younger than every stage waited for so far (PD nk pieces issued since)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                if constexpr (HAS_RES) asm volatile("" : "+v"(rq[mi][0]), "+v"(rq[mi][1]), "+v"(rq[mi][2]), "+v"(rq[mi][3]));
+                if constexpr (HAS_GATE) asm volatile("" : "+v"(eq[mi][0]), "+v"(eq[mi][1]), "+v"(eq[mi][2]), "+v"(eq[mi][3]));
+            }
+        }
+        const unsigned soY = (unsigned)((m0 * a.ldy + co0) * 2);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    float lo[4], hi[4];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int g = 2 * gp + e;
+                        const float4 bv = *(const float4*)(bias_lds + co0 + 64 * wn + 32 * ni + 8 * g + 4 * lh);
+                        float* d = e ? hi : lo;
+                        d[0] = acc[mi][ni][4 * g + 0] + bv.x; d[1] = acc[mi][ni][4 * g + 1] + bv.y;
+                        d[2] = acc[mi][ni][4 * g + 2] + bv.z; d[3] = acc[mi][ni][4 * g + 3] + bv.w;
+                    }
+                    float o[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo[i]), __float_as_uint(hi[i]), false, false);
+                        o[i] = __uint_as_float(sw[0]);
+                        o[4 + i] = __uint_as_float(sw[1]);
+                    }
+                    if constexpr (HAS_RES) {
+                        const u32x4_t q = rq[mi][2 * ni + gp];
+                        float rv[8];
+                        unpack16<bf16_t>(make_uint4(q.x, q.y, q.z, q.w), rv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += rv[e];
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = fmaxf(o[e], 0.f);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = act_apply(o[e], a.act);
+                    }
+                    if constexpr (HAS_GATE) {
+                        const u32x4_t q = eq[mi][2 * ni + gp];
+                        float ev[8];
+                        unpack16<bf16_t>(make_uint4(q.x, q.y, q.z, q.w), ev);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = act_gate(o[e], ev[e], a.egate_act);
+                    }
+                    const uint4 pk = pack16<bf16_t>(o);
+                    u32x4_t pv; pv.x = pk.x; pv.y = pk.y; pv.z = pk.z; pv.w = pk.w;
+                    if (ni == 0 && gp == 0) st16<0>(pv, voY[mi], rsY, soY);
+                    else if (ni == 0) st16<32>(pv, voY[mi], rsY, soY);
+                    else if (gp == 0) st16<64>(pv, voY[mi], rsY, soY);
+                    else st16<96>(pv, voY[mi], rsY, soY);
+                }
+        h_post[0] = PS;
+        c_ct += dct; const int cy = c_ct >= a.n_ct ? 1 : 0; c_ct -= cy * a.n_ct; c_pt += dpt + cy;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the ring's trailing (all-zero) pieces must land before this LDS allocation is released
 }
 
 // =================================================================================================
@@ -986,6 +1254,44 @@ extern "C" int wu_conv1x1_fwd(const void* x, int ldx, const void* w, const float
     WU_REQUIRE(grid < (1ll << 31), "conv1x1_fwd: grid too large");
     hipStream_t s = (hipStream_t)stream;
     wu_prof_pre(WU_FAM_CONV1X1, s);
+    // Round 4: the persistent LDS-DMA form (128 x 128 tiles) where it applies.  Option 15: low 3 bits = ring depth D (0 = off), bit 3 = eight waves per workgroup instead
+    // of four (D = 2: two workgroups per CU; else one), the rest = the least number of tiles (below it the 64 x 64 tiles fill more of the chip)
+    {
+        const int pd = g_wu_opt[WU_OPT_PW3] & 7, pw8 = (g_wu_opt[WU_OPT_PW3] >> 3) & 1, min_items = g_wu_opt[WU_OPT_PW3] >> 4;
+        const long long items = ((a.M + pw3::TM - 1) / pw3::TM) * (Cout / pw3::TN);
+        const long long max_ld = std::max(std::max(ldx, ldy), std::max(residual ? ldres : 0, egate ? ldegate : 0));
+        if (pd >= 2 && pd <= 4 && dtype == WU_BF16 && in_stride == 1 && out_stride == 1 && Cout % pw3::TN == 0 && Cout <= pw3::kMaxCout &&
+            items >= min_items && items < (1ll << 30) && (a.M + pw3::TM) * max_ld * 2 < (1ll << 31) && (long long)Cout * Cin * 2 < (1ll << 31)) {
+            pw3::Args p;
+            p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.res = (const bf16_t*)residual; p.egate = (const bf16_t*)egate; p.y = (bf16_t*)y;
+            p.ldx = ldx; p.ldres = residual ? ldres : 0; p.ldegate = egate ? ldegate : 0; p.ldy = ldy;
+            p.M = (int)a.M; p.Cin = Cin; p.Cout = Cout; p.act = act; p.egate_act = egate_act; p.n_ct = Cout / pw3::TN; p.items = (int)items;
+            const int per_cu = pd == 2 ? 2 : 1;
+            const int grid3 = (int)std::min<long long>(items, (long long)per_cu * wu_num_cus());
+            const size_t smem3 = (size_t)pd * pw3::kStage + (size_t)Cout * 4;
+            const bool hr = residual != nullptr, hg = egate != nullptr && egate_act != WU_ACT_NONE;
+#define WU_PW3_GO(NW_, D_, R_, G_)                                                                                                      \
+            do {                                                                                                                         \
+                static bool attr3 = false;                                                                                               \
+                if (!attr3) { (void)hipFuncSetAttribute((const void*)conv1x1_pw3_kernel<NW_, D_, R_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, D_ * pw3::kStage + pw3::kMaxCout * 4); attr3 = true; } \
+                hipLaunchKernelGGL((conv1x1_pw3_kernel<NW_, D_, R_, G_>), dim3((unsigned)grid3), dim3(NW_ * 64), smem3, s, p);         \
+            } while (0)
+#define WU_PW3_D(NW_, D_)                                                        \
+            do {                                                                 \
+                if (hr && hg) WU_PW3_GO(NW_, D_, true, true);                    \
+                else if (hr) WU_PW3_GO(NW_, D_, true, false);                    \
+                else if (hg) WU_PW3_GO(NW_, D_, false, true);                    \
+                else WU_PW3_GO(NW_, D_, false, false);                           \
+            } while (0)
+            if (pw8) { if (pd == 2) WU_PW3_D(8, 2); else if (pd == 3) WU_PW3_D(8, 3); else WU_PW3_D(8, 4); }
+            else { if (pd == 2) WU_PW3_D(4, 2); else if (pd == 3) WU_PW3_D(4, 3); else WU_PW3_D(4, 4); }
+#undef WU_PW3_D
+#undef WU_PW3_GO
+            wu_prof_post(WU_FAM_CONV1X1, s, 2.0 * (double)a.M * Cin * Cout, ((double)a.M * (Cin + Cout * (residual ? 2 : 1)) + (double)Cin * Cout) * esz);
+            WU_LAUNCH_CHECK("conv1x1_pw3");
+            return 0;
+        }
+    }
     static thread_local bool attr_set = false;
     if (!attr_set) {
 #define WU_PW_ATTR(TM_) (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<bf16_t, TM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + kTN) * kKB); \

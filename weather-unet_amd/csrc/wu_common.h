@@ -48,6 +48,7 @@ extern void* g_wu_dbg_ptr;
 #define WU_OPT_PW_TILE 12
 #define WU_OPT_IMG3_TILED 13
 #define WU_OPT_S2_DGRAD_PARITY 14
+#define WU_OPT_PW3 15
 
 int wu_num_cus();   // compute units of the current device (wu_prof.hip), cached
 

@@ -57,6 +57,12 @@ def conv1x1(x, w, bias, y, act=NONE, residual=None, egate=None, egate_act=NONE, 
     return y
 
 
+# The pointwise convs with Cout % 128 == 0 and at least 128 tiles of 128 x 128 run on the persistent LDS-DMA kernel (conv1x1_pw3_kernel, round 4:
+# bit-identical to the 64 x 64-tile kernel, 1.2-1.7x faster on the layer2-4 shapes).  WU_PW_PERSIST=0 puts every call back on the old kernel (A/B).
+if os.environ.get("WU_PW_PERSIST", "1") == "0":
+    _lib.call("wu_set_option", 15, 0)
+
+
 # conv3 + residual + ReLU of a block and conv1 + ReLU of the next in ONE launch (and the mirror-image pair in backward).  OFF by default:
 # measured (round 4, profiles/r04_chain_bench.txt, r04_gan_chain_ab.txt) the chained launch is bit-identical but not faster -- every
 # 32-row workgroup streams both weight matrices (1 MB at layer3) from L2, 256 workgroups at once: 28 us against 30 us for the two launches
