@@ -413,3 +413,48 @@ def test_pointwise_persistent_dma_kernel_is_bit_identical(shape, depth):
     finally:
         _lib.call("wu_set_option", OPT_PW3, 2 + 8 + (128 << 4))        # the library's default (wu_prof.hip)
         _lib.call("wu_set_option", OPT_GRID, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 64, 128, 32, 32), (3, 128, 256, 17, 23), (1, 256, 512, 9, 16), (2, 128, 128, 45, 70), (1, 512, 512, 16, 16)])
+def test_stride2_conv_on_the_gathered_row_pipeline(shape):
+    """wu_conv3x3_fwd, stride 2, bf16: the gathered-row form of the persistent LDS-DMA GEMM (round 4, conv1x1_pw3_kernel<.., CONV>) against
+    F.conv2d on the bf16-rounded operands (tolerance of the bf16 conv tests) and against the register-staged kernel it replaces (option 15 = 0;
+    the K order differs -- (64-channel chunk, tap) against (32-channel chunk, tap) -- so the two may differ in the last bf16 digit): bias +
+    LeakyReLU (SNDisc), bias + ReLU with an output gate, on 5 workgroups (several tiles per workgroup) and on the whole chip; odd image sizes."""
+    import torch.nn.functional as F
+    from wu import _lib, kernels as K
+    from wu.layout import as_nhwc, empty_nhwc
+    dev = _dev()
+    bf = torch.bfloat16
+    n, cin, cout, h, w = shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    x32 = _rand((n, cin, h, w), 51).to(bf).float()
+    wt = _rand((cout, cin, 3, 3), 52, -0.05, 0.05)
+    b = _rand((cout,), 53, -0.2, 0.2)
+    x = as_nhwc(x32.to(dev), _lib.BF16)
+    wf, _ = K.pack_conv3x3(wt.to(dev), _lib.BF16)
+    gate = as_nhwc(_rand((n, cout, ho, wo), 54).to(dev), _lib.BF16)
+    ref = F.conv2d(x32, wt.to(bf).float(), b, stride=2, padding=1)
+    OPT_PW3, OPT_GRID, DEFAULT = 15, 10, 2 + 8 + (128 << 4)
+    try:
+        for act, eg in ((K.ACT_LEAKY, None), (K.ACT_RELU, gate)):
+            want = F.leaky_relu(ref, 0.2) if act == K.ACT_LEAKY else F.relu(ref) * (gate.float().cpu() > 0).float()
+            outs = []
+            for opt, cus in ((0, 0), (2 + 8, 0), (2 + 8, 5)):
+                _lib.call("wu_set_option", OPT_PW3, opt)
+                _lib.call("wu_set_option", OPT_GRID, cus)
+                ybuf = empty_nhwc(n, cout + 64, ho, wo, bf, dev)
+                ybuf.fill_(7.0)
+                K.conv3x3(x, wf, b.to(dev), ybuf[:, :cout], 2, act, egate=eg, egate_act=K.ACT_RELU if eg is not None else K.ACT_NONE)
+                torch.cuda.synchronize()
+                assert bool((ybuf[:, cout:] == 7.0).all())
+                outs.append(ybuf[:, :cout].float().cpu())
+            scale = max(1.0, want.abs().max().item())
+            for o in outs:
+                assert (o - want).abs().max().item() <= 1.5e-2 * scale
+            assert torch.equal(outs[1], outs[2]), "5 workgroups against the whole chip"
+            assert (outs[0] - outs[1]).abs().max().item() <= 8e-3 * scale, "gathered-row form against the register-staged kernel"
+    finally:
+        _lib.call("wu_set_option", OPT_PW3, DEFAULT)
+        _lib.call("wu_set_option", OPT_GRID, 0)

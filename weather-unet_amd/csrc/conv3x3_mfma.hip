@@ -395,6 +395,14 @@ extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, cons
         return 0;
     }
     wu_prof_pre(fam, s);
+    // Round 4: stride 2 goes to the gathered-row form of the persistent LDS-DMA GEMM (option 15; resnet.hip) where its shape allows
+    if (dtype == WU_BF16 && !m && stride == 2 && (g_wu_opt[WU_OPT_PW3] & 7) &&
+        conv3x3_gather_launch(x, ldx, w_packed, bias, y, ldy, egate, ldegate, egate_act, N, H, W, Cin, Cout, stride, act, s) == 0) {
+        const double pix = (double)N * a.Ho * a.Wo;
+        wu_prof_post(fam, s, 2.0 * pix * Cout * 9.0 * Cin, ((double)N * H * W * Cin + pix * Cout) * esz + 9.0 * Cin * Cout * esz);
+        WU_LAUNCH_CHECK("conv3x3 (gathered rows)");
+        return 0;
+    }
     if (dtype == WU_BF16) {
         if (stride == 1) { if (m) launch_conv<bf16_t, 1, true>(a, lds, (int)grid, s); else launch_conv<bf16_t, 1, false>(a, lds, (int)grid, s); }
         else launch_conv<bf16_t, 2, false>(a, lds, (int)grid, s);

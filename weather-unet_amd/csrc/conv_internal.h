@@ -19,3 +19,8 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
 // rotated 9-slab pack [tap'][Cin][Cout]; dx: (N, Cin, H, W), optionally gated by act'(egate) in the epilogue.
 int conv_s2_dgrad_parity_launch(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx, const void* egate, int ldegate, int egate_act,
                                 int N, int H, int W, int Cin, int Cout, int dtype, hipStream_t s);
+
+// 3 x 3 conv, stride 1 or 2 (bf16, unmasked; Cin % 64 == 0, Cout % 128 == 0), on the persistent LDS-DMA GEMM pipeline of the pointwise convs with
+// gathered activation rows (resnet.hip, conv1x1_pw3_kernel<.., CONV>).  0 = launched, 1 = not applicable (fall back to conv3x3_mfma_kernel).
+int conv3x3_gather_launch(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy, const void* egate, int ldegate, int egate_act,
+                          int N, int H, int W, int Cin, int Cout, int stride, int act, hipStream_t s);

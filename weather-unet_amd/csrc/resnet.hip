@@ -347,6 +347,7 @@ struct Args {
     int ldx, ldres, ldegate, ldy;
     int M, Cin, Cout, act, egate_act;
     int n_ct, items;            // cout tiles; pixel tiles x cout tiles
+    int H, W, Ho, Wo, stride;   // CONV instances: the 3 x 3 conv's input / output image (M = N Ho Wo rows)
 };
 
 template <int OFF> __device__ __forceinline__ u32x4_t ld16(unsigned voff, wu_rsrc_t rs, unsigned soff) {
@@ -383,7 +384,11 @@ __device__ __forceinline__ void vm_wait(int n) {
 
 // NW waves: 4 (2 x 2, 64 pixels x 64 couts each) or 8 (4 x 2, 32 pixels x 64 couts each: two waves per SIMD with ONE workgroup per CU, so
 // that the whole LDS can be ring)
-template <int NW, int D, bool HAS_RES, bool HAS_GATE>
+// CONV (round 4): the same pipeline as a 3 x 3 conv, stride 1 or 2 -- K runs over (64-channel chunk, tap), the weight rows of a step are slab `tap` of
+// the [9][Cout][Cin] pack, and its activation rows are GATHERED: row r of the tile is output pixel (n, oy, ox), the DMA lane that fetches it reads input
+// pixel (n, s oy + dy - 1, s ox + dx - 1) or, outside the image, is pushed out of the descriptor's range (zeros).  Every tap re-reads its rows from L2 (no
+// halo reuse): 2.25x the input at stride 2, where it replaces conv3x3_mfma_kernel<T, 2> (one workgroup per CU, register staging: 290-510 TFLOP/s).
+template <int NW, int D, bool HAS_RES, bool HAS_GATE, bool CONV = false>
 __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(const pw3::Args a) {
     using namespace pw3;
     constexpr int WM = NW == 8 ? 4 : 2, WN = NW / WM, MI = TM / (32 * WM), NI = TN / (32 * WN);
@@ -400,14 +405,19 @@ __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(co
     const int l31 = lane & 31, lh = lane >> 5;
     const int G = (int)gridDim.x;
     const int wg = xcd_remap(blockIdx.x, G);
-    const int nk = a.Cin / 64;
+    const int nchunks = a.Cin / 64;
+    const int nk = CONV ? 9 * nchunks : nchunks;
 
     for (int i = tid; i < a.Cout; i += NT) bias_lds[i] = a.bias ? a.bias[i] : 0.f;
     __syncthreads();
 
     // ---- descriptors and tile-invariant per-lane byte offsets ----
-    const wu_rsrc_t rsA = wu_make_rsrc(a.x, (unsigned)((((size_t)a.M - 1) * a.ldx + a.Cin) * 2));
-    const wu_rsrc_t rsW = wu_make_rsrc(a.w, (unsigned)((size_t)a.Cout * a.Cin * 2));
+    // (CONV: the base is shifted back by one row + one pixel so that a tap's offset (dy W + dx) is never negative; may point before the tensor,
+    //  never dereferenced there -- such lanes are out of the image and pushed out of range)
+    const size_t a_shift = CONV ? ((size_t)a.W + 1) * a.ldx * 2 : 0;
+    const size_t a_rows = CONV ? (size_t)(a.M / (a.Ho * a.Wo)) * a.H * a.W : (size_t)a.M;
+    const wu_rsrc_t rsA = wu_make_rsrc((const char*)a.x - a_shift, (unsigned)(a_shift + ((a_rows - 1) * a.ldx + a.Cin) * 2));
+    const wu_rsrc_t rsW = wu_make_rsrc(a.w, (unsigned)((size_t)(CONV ? 9 : 1) * a.Cout * a.Cin * 2));
     const wu_rsrc_t rsY = wu_make_rsrc(a.y, (unsigned)((((size_t)a.M - 1) * a.ldy + a.Cout) * 2));
     const wu_rsrc_t rsR = wu_make_rsrc(HAS_RES ? a.res : a.y, HAS_RES ? (unsigned)((((size_t)a.M - 1) * a.ldres + a.Cout) * 2) : 0u);
     const wu_rsrc_t rsE = wu_make_rsrc(HAS_GATE ? a.egate : a.y, HAS_GATE ? (unsigned)((((size_t)a.M - 1) * a.ldegate + a.Cout) * 2) : 0u);
@@ -432,21 +442,62 @@ __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(co
 
     // ---- the two cursors over this workgroup's items (wg, wg + G, ...; cout tile fastest), carried digit by digit ----
     const int dct = G % a.n_ct, dpt = G / a.n_ct;
-    int f_item = wg, f_ct = wg % a.n_ct, f_pt = wg / a.n_ct, f_k = 0;
+    int f_item = wg, f_ct = wg % a.n_ct, f_pt = wg / a.n_ct, f_k = 0, f_tap = 0;     // (CONV: f_k counts chunks, f_tap the tap inside the chunk)
     bool f_alive = f_item < a.items;
+    unsigned baseA[PA], vbits[PA];       // CONV: byte offset of the fetch tile's rows at tap (0, 0) in the shifted descriptor; bit t = tap t is inside the image
+    auto conv_tile = [&](int pt) __attribute__((always_inline)) {
+        const int hw = a.Ho * a.Wo;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const int row = 8 * (wave + NW * j) + (lane >> 3);
+            const int sl = (lane & 7) ^ ((row >> 1) & 7);
+            const int p = pt * TM + row;
+            const int n = p / hw, rem = p - n * hw, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            const int iy0 = oy * a.stride, ix0 = ox * a.stride;
+            baseA[j] = (unsigned)((((n * a.H + iy0) * a.W + ix0) * a.ldx) * 2 + sl * 16);
+            unsigned b = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const bool ok = p < a.M && (unsigned)(iy0 + t / 3 - 1) < (unsigned)a.H && (unsigned)(ix0 + t % 3 - 1) < (unsigned)a.W;
+                b |= (ok ? 1u : 0u) << t;
+            }
+            vbits[j] = b;
+        }
+    };
+    if (CONV && f_alive) conv_tile(f_pt);
     auto fetch = [&](int stage) __attribute__((always_inline)) {
         const unsigned kill = f_alive ? 0u : kWuOOB;
-        const unsigned soA = (unsigned)((f_pt * TM * a.ldx + f_k * 64) * 2) | kill;
-        const unsigned soW = (unsigned)((f_ct * TN * a.Cin + f_k * 64) * 2) | kill;
         const unsigned lds = smem_base + stage * kStage + wave * 1024;
+        if constexpr (CONV) {
+            const int dy = f_tap >= 6 ? 2 : (f_tap >= 3 ? 1 : 0), dx = f_tap - 3 * dy;
+            const unsigned soA = (unsigned)(((dy * a.W + dx) * a.ldx + f_k * 64) * 2) | kill;
+            const unsigned soW = (unsigned)(((f_tap * a.Cout + f_ct * TN) * a.Cin + f_k * 64) * 2) | kill;
 #pragma unroll
-        for (int j = 0; j < PA; ++j) wu_dma16b(voA[j], rsA, soA, __builtin_amdgcn_readfirstlane(lds + j * NW * 1024));
+            for (int j = 0; j < PA; ++j)
+                wu_dma16b(((vbits[j] >> f_tap) & 1u) ? baseA[j] : kWuOOB, rsA, soA, __builtin_amdgcn_readfirstlane(lds + j * NW * 1024));
 #pragma unroll
-        for (int j = 0; j < PA; ++j) wu_dma16b(voW[j], rsW, soW, __builtin_amdgcn_readfirstlane(lds + TM * kKB + j * NW * 1024));
-        if (f_alive && ++f_k == nk) {
-            f_k = 0; f_item += G;
-            f_ct += dct; const int cy = f_ct >= a.n_ct ? 1 : 0; f_ct -= cy * a.n_ct; f_pt += dpt + cy;
-            f_alive = f_item < a.items;
+            for (int j = 0; j < PA; ++j) wu_dma16b(voW[j], rsW, soW, __builtin_amdgcn_readfirstlane(lds + TM * kKB + j * NW * 1024));
+            if (f_alive && ++f_tap == 9) {
+                f_tap = 0;
+                if (++f_k == nchunks) {
+                    f_k = 0; f_item += G;
+                    f_ct += dct; const int cy = f_ct >= a.n_ct ? 1 : 0; f_ct -= cy * a.n_ct; f_pt += dpt + cy;
+                    f_alive = f_item < a.items;
+                    if (f_alive) conv_tile(f_pt);
+                }
+            }
+        } else {
+            const unsigned soA = (unsigned)((f_pt * TM * a.ldx + f_k * 64) * 2) | kill;
+            const unsigned soW = (unsigned)((f_ct * TN * a.Cin + f_k * 64) * 2) | kill;
+#pragma unroll
+            for (int j = 0; j < PA; ++j) wu_dma16b(voA[j], rsA, soA, __builtin_amdgcn_readfirstlane(lds + j * NW * 1024));
+#pragma unroll
+            for (int j = 0; j < PA; ++j) wu_dma16b(voW[j], rsW, soW, __builtin_amdgcn_readfirstlane(lds + TM * kKB + j * NW * 1024));
+            if (f_alive && ++f_k == nk) {
+                f_k = 0; f_item += G;
+                f_ct += dct; const int cy = f_ct >= a.n_ct ? 1 : 0; f_ct -= cy * a.n_ct; f_pt += dpt + cy;
+                f_alive = f_item < a.items;
+            }
         }
     };
 
@@ -1212,6 +1263,37 @@ inline int grid_cap(long long total, int block = 256, int cap = 256 * 16) {
 }
 
 }  // namespace
+
+// 3 x 3 conv (stride 1 or 2, bf16, unmasked) on the persistent LDS-DMA GEMM pipeline with gathered activation rows (conv1x1_pw3_kernel<.., CONV>):
+// 0 = launched, 1 = not applicable (the caller falls back to conv3x3_mfma_kernel).  w_packed: the [9][Cout][Cin] forward pack.
+int conv3x3_gather_launch(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy, const void* egate, int ldegate, int egate_act,
+                          int N, int H, int W, int Cin, int Cout, int stride, int act, hipStream_t s) {
+    const int pd = g_wu_opt[WU_OPT_PW3] & 7, min_items = g_wu_opt[WU_OPT_PW3] >> 4;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const long long M = (long long)N * Ho * Wo;
+    const long long items = ((M + pw3::TM - 1) / pw3::TM) * (Cout / pw3::TN);
+    const bool hg = egate != nullptr && egate_act != WU_ACT_NONE;
+    if (pd == 0 || Cin % 64 != 0 || Cout % pw3::TN != 0 || Cout > pw3::kMaxCout || items < min_items || items >= (1ll << 30)) return 1;
+    if (((long long)N * H * W + W + 1 + pw3::TM * stride * stride) * ldx * 2 >= (1ll << 31) || (M + pw3::TM) * std::max(ldy, hg ? ldegate : 0) * 2 >= (1ll << 31) ||
+        9ll * Cout * Cin * 2 >= (1ll << 31)) return 1;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w_packed | (uintptr_t)egate) % 16 != 0 || (ldx * 2) % 16 != 0 || (ldy * 2) % 16 != 0 || (hg && (ldegate * 2) % 16 != 0)) return 1;
+    pw3::Args p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.bias = bias; p.res = nullptr; p.egate = (const bf16_t*)egate; p.y = (bf16_t*)y;
+    p.ldx = ldx; p.ldres = 0; p.ldegate = hg ? ldegate : 0; p.ldy = ldy;
+    p.M = (int)M; p.Cin = Cin; p.Cout = Cout; p.act = act; p.egate_act = egate_act; p.n_ct = Cout / pw3::TN; p.items = (int)items;
+    p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.stride = stride;
+    const int grid = (int)std::min<long long>(items, 2ll * wu_num_cus());
+    const size_t smem = (size_t)2 * pw3::kStage + (size_t)Cout * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv1x1_pw3_kernel<8, 2, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * pw3::kStage + pw3::kMaxCout * 4);
+        (void)hipFuncSetAttribute((const void*)conv1x1_pw3_kernel<8, 2, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * pw3::kStage + pw3::kMaxCout * 4);
+        attr_set = true;
+    }
+    if (hg) hipLaunchKernelGGL((conv1x1_pw3_kernel<8, 2, false, true, true>), dim3((unsigned)grid), dim3(512), smem, s, p);
+    else hipLaunchKernelGGL((conv1x1_pw3_kernel<8, 2, false, false, true>), dim3((unsigned)grid), dim3(512), smem, s, p);
+    return 0;
+}
 
 #define DISPATCH_T(dtype, ...)                                      \
     do {                                                            \
