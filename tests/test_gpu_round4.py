@@ -212,21 +212,30 @@ def test_stride2_dgrad_parity_classes(precision, shape, gated):
     gyd = as_nhwc(gy.to(dev), code)
     eg = as_nhwc(xg.to(dev), code) if gated else None
     res = {}
+    PW3_DEFAULT = 2 + 8 + (128 << 5)
+    # (option 14, option 15): the classes on the gathered-row LDS-DMA pipeline (bf16; forced for every size, on the whole chip and on 3 workgroups),
+    # the classes on the register-staged tap-list kernel, the zero-stuffing path
+    paths = {"gathered": (1, 16 + 2 + 8, 0), "gathered, 3 workgroups": (1, 16 + 2 + 8, 3), "tap lists": (1, 0, 0), "zero stuffing": (0, 0, 0)}
     try:
-        for opt in (1, 0):
-            _lib.call("wu_set_option", 14, opt)
+        for name, (o14, o15, cus) in paths.items():
+            _lib.call("wu_set_option", 14, o14)
+            _lib.call("wu_set_option", 15, o15)
+            _lib.call("wu_set_option", 10, cus)
             dx = empty_nhwc(n, cin, h, w, dt, dev)
             dx.fill_(float("nan"))
             K.conv3x3_s2_dgrad(gyd, wd, dx, egate=eg, egate_act=K.ACT_LEAKY if gated else K.ACT_NONE)
             torch.cuda.synchronize()
-            res[opt] = dx.float().cpu()
+            res[name] = dx.float().cpu()
     finally:
         _lib.call("wu_set_option", 14, 1)
+        _lib.call("wu_set_option", 15, PW3_DEFAULT)
+        _lib.call("wu_set_option", 10, 0)
     tol = (2e-4 if precision == "fp32" else 1.2e-2) * max(1.0, want.abs().max().item())
-    for opt in (1, 0):
-        assert not torch.isnan(res[opt]).any(), f"path {opt} left sites unwritten"
-        err = (res[opt] - want).abs().max().item()
-        assert err <= tol, f"path {opt}: {err} vs tolerance {tol}"
+    for name in paths:
+        assert not torch.isnan(res[name]).any(), f"{name}: sites left unwritten"
+        err = (res[name] - want).abs().max().item()
+        assert err <= tol, f"{name}: {err} vs tolerance {tol}"
+    assert torch.equal(res["gathered"], res["gathered, 3 workgroups"])
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -371,14 +380,14 @@ def test_pool_epilogue_bits_and_maxpool_backward_from_bits(shape, sliced):
 
 # (N, Cin, Cout, H, W): the estimator's stride-1 pointwise shapes at a small batch, a ragged row count, a single K step and a single tile
 PW3_SHAPES = [(2, 256, 1024, 16, 16), (2, 1024, 256, 16, 16), (3, 128, 512, 10, 10), (1, 512, 2048, 8, 8), (1, 2048, 512, 8, 8),
-              (2, 64, 256, 24, 20), (2, 512, 128, 9, 7), (1, 192, 128, 5, 5)]
+              (2, 64, 256, 24, 20), (2, 512, 128, 9, 7), (1, 192, 128, 5, 5), (2, 256, 64, 24, 20), (1, 128, 192, 9, 9), (3, 64, 64, 16, 16)]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("depth", [2, 3, 4, 8 + 2, 8 + 3, 8 + 4])
+@pytest.mark.parametrize("depth", [16 + 2, 16 + 3, 16 + 4, 16 + 8 + 2, 16 + 8 + 3, 16 + 8 + 4])
 @pytest.mark.parametrize("shape", PW3_SHAPES)
 def test_pointwise_persistent_dma_kernel_is_bit_identical(shape, depth):
-    """conv1x1_pw3_kernel (round 4: 128 x 128 tiles, LDS-DMA ring of `depth & 7` stages, four or -- bit 3 -- eight waves, persistent workgroups, counted waits) against
+    """conv1x1_pw3_kernel (round 4: 128 x 128 tiles, LDS-DMA ring of `depth & 7` stages, four or -- bit 3 -- eight waves, 64-cout tiles allowed -- bit 4 --, persistent workgroups, counted waits) against
     conv1x1_mfma_kernel on the same operands, bitwise: plain; bias + residual + ReLU (the forward of a Bottleneck's conv3); gate only (data
     gradient of conv3); residual + gate (data gradient of conv1 plus the identity path).  Outputs and residuals are channel slices of wider
     buffers (ld > C), the grid is held at 5 workgroups so that every workgroup walks several tiles and the ring wraps across tile borders."""
@@ -411,12 +420,13 @@ def test_pointwise_persistent_dma_kernel_is_bit_identical(shape, depth):
             assert torch.equal(outs[0], outs[2]), f"case {ci}: persistent kernel on 5 workgroups differs"
             assert bool((outs[0][:, cout:] == 7.0).all())
     finally:
-        _lib.call("wu_set_option", OPT_PW3, 2 + 8 + (128 << 4))        # the library's default (wu_prof.hip)
+        _lib.call("wu_set_option", OPT_PW3, 2 + 8 + (128 << 5))        # the library's default (wu_prof.hip)
         _lib.call("wu_set_option", OPT_GRID, 0)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 64, 128, 32, 32), (3, 128, 256, 17, 23), (1, 256, 512, 9, 16), (2, 128, 128, 45, 70), (1, 512, 512, 16, 16)])
+@pytest.mark.parametrize("shape", [(2, 64, 128, 32, 32), (3, 128, 256, 17, 23), (1, 256, 512, 9, 16), (2, 128, 128, 45, 70), (1, 512, 512, 16, 16),
+                                   (2, 64, 64, 20, 28), (1, 128, 192, 11, 7)])
 def test_stride2_conv_on_the_gathered_row_pipeline(shape):
     """wu_conv3x3_fwd, stride 2, bf16: the gathered-row form of the persistent LDS-DMA GEMM (round 4, conv1x1_pw3_kernel<.., CONV>) against
     F.conv2d on the bf16-rounded operands (tolerance of the bf16 conv tests) and against the register-staged kernel it replaces (option 15 = 0;
@@ -436,12 +446,12 @@ def test_stride2_conv_on_the_gathered_row_pipeline(shape):
     wf, _ = K.pack_conv3x3(wt.to(dev), _lib.BF16)
     gate = as_nhwc(_rand((n, cout, ho, wo), 54).to(dev), _lib.BF16)
     ref = F.conv2d(x32, wt.to(bf).float(), b, stride=2, padding=1)
-    OPT_PW3, OPT_GRID, DEFAULT = 15, 10, 2 + 8 + (128 << 4)
+    OPT_PW3, OPT_GRID, DEFAULT = 15, 10, 2 + 8 + (128 << 5)
     try:
         for act, eg in ((K.ACT_LEAKY, None), (K.ACT_RELU, gate)):
             want = F.leaky_relu(ref, 0.2) if act == K.ACT_LEAKY else F.relu(ref) * (gate.float().cpu() > 0).float()
             outs = []
-            for opt, cus in ((0, 0), (2 + 8, 0), (2 + 8, 5)):
+            for opt, cus in ((0, 0), (16 + 2 + 8, 0), (16 + 2 + 8, 5)):
                 _lib.call("wu_set_option", OPT_PW3, opt)
                 _lib.call("wu_set_option", OPT_GRID, cus)
                 ybuf = empty_nhwc(n, cout + 64, ho, wo, bf, dev)

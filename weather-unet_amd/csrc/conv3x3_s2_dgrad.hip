@@ -47,7 +47,11 @@ extern "C" int wu_conv3x3_s2_dgrad(const void* dy, int lddy, const void* y, int 
         ((uintptr_t)w_dgrad % 16) == 0 && (size_t)H * W * (size_t)lddx < (1ull << 31)) {
         if (egate) WU_REQUIRE(((uintptr_t)egate % 16) == 0 && (ldegate * esz) % 16 == 0 && ldegate >= Cin, "conv3x3_s2_dgrad: bad egate");
         wu_prof_pre(WU_FAM_CONV_S2, s);
-        const int rc = conv_s2_dgrad_parity_launch(dy, lddy, w_dgrad, dx, lddx, egate, ldegate, egate_act, N, H, W, Cin, Cout, dtype, s);
+        // bf16: the classes on the persistent LDS-DMA GEMM with gathered rows (resnet.hip, option 15); else the register-staged tap-list kernel
+        int rc = 1;
+        if (dtype == WU_BF16 && (g_wu_opt[WU_OPT_PW3] & 7))
+            rc = conv_s2_dgrad_gather_launch(dy, lddy, w_dgrad, dx, lddx, egate, ldegate, egate_act, N, H, W, Cin, Cout, s);
+        if (rc != 0) rc = conv_s2_dgrad_parity_launch(dy, lddy, w_dgrad, dx, lddx, egate, ldegate, egate_act, N, H, W, Cin, Cout, dtype, s);
         if (rc == 0) {
             const double pix = (double)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
             wu_prof_post(WU_FAM_CONV_S2, s, 2.0 * pix * Cout * 9.0 * Cin, (pix * Cout + (double)N * H * W * Cin + 9.0 * Cin * Cout) * esz);

@@ -24,3 +24,6 @@ int conv_s2_dgrad_parity_launch(const void* dy, int lddy, const void* w_dgrad, v
 // gathered activation rows (resnet.hip, conv1x1_pw3_kernel<.., CONV>).  0 = launched, 1 = not applicable (fall back to conv3x3_mfma_kernel).
 int conv3x3_gather_launch(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy, const void* egate, int ldegate, int egate_act,
                           int N, int H, int W, int Cin, int Cout, int stride, int act, hipStream_t s);
+// ... and the data gradient of a stride-2 conv (bf16): the four parity classes above as one launch of that pipeline, outputs scattered to their sites.
+int conv_s2_dgrad_gather_launch(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx, const void* egate, int ldegate, int egate_act,
+                                int N, int H, int W, int Cin, int Cout, hipStream_t s);

@@ -337,8 +337,7 @@ __global__ __launch_bounds__(256, TM == 256 ? 2 : (TM == 128 ? 3 : 4)) void conv
 // never sees an outstanding load it would drain the ring for.  Same MFMA operand mapping, K order and epilogue arithmetic as
 // conv1x1_mfma_kernel: bit-identical results (tests/test_gpu_round4.py).
 namespace pw3 {
-constexpr int TM = 128, TN = 128;
-constexpr int kStage = (TM + TN) * kKB;          // 32 KiB: activation rows, then weight rows
+constexpr int TM = 128;                          // pixel rows per tile; cout columns per tile TN = 128 or 64 (template parameter)
 constexpr int kMaxCout = 2048;                   // bias image in LDS
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -346,56 +345,92 @@ struct Args {
     const bf16_t* x; const bf16_t* w; const float* bias; const bf16_t* res; const bf16_t* egate; bf16_t* y;
     int ldx, ldres, ldegate, ldy;
     int M, Cin, Cout, act, egate_act;
-    int n_ct, items;            // cout tiles; pixel tiles x cout tiles
-    int H, W, Ho, Wo, stride;   // CONV instances: the 3 x 3 conv's input / output image (M = N Ho Wo rows)
+    int n_ct, items;            // cout tiles; pixel tiles x cout tiles x classes
+    // CONV instances.  Rows = the Ho x Wo grid of every image (M = N Ho Wo); tap t of class c reads source pixel (s oy + dy - 1, s ox + dx - 1) of the
+    // H x W image and multiplies by slab `slab` of the [9][Cout][Cin] pack; row (n, oy, ox) lands at (oy osy + ooy[c], ox osx + oox[c]) of the OH x OW
+    // output image (skipped outside).  Forward conv: one class of nine taps, identity output map.  Data gradient of a stride-2 conv: four parity
+    // classes of 4 / 2 / 2 / 1 taps over the dY grid (conv_internal.h).  cls_tap packs (dy, dx, slab) as dy | dx << 2 | slab << 4.
+    int H, W, Ho, Wo, stride;
+    int ncls, cls_ntaps[4], cls_ooy[4], cls_oox[4];
+    unsigned cls_tap[4][9];
+    int osy, osx, OH, OW;
 };
 
+// Vector-memory operations from inline asm.  The hazard recogniser does not see into asm: an SGPR operand (descriptor, scalar offset) that the
+// compiler has just restored from a spill lane with v_readlane_b32 -- it does in the register-hungry instances -- must be 5 wait states old before
+// a VMEM instruction reads it ("VALU writes SGPR -> VMEM reads that SGPR"; seen as a wrong first load of a group, the later ones correct), and the
+// data registers of a 128-bit store may not be rewritten in the next cycle.  Every block therefore carries its own s_nop.
 template <int OFF> __device__ __forceinline__ u32x4_t ld16(unsigned voff, wu_rsrc_t rs, unsigned soff) {
     u32x4_t v;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
     return v;
 }
 template <int OFF> __device__ __forceinline__ void st16(u32x4_t v, unsigned voff, wu_rsrc_t rs, unsigned soff) {
-    // s_nop: the data registers of a 128-bit store may not be rewritten in the next cycle (the hazard recogniser does not see into asm)
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
 }
-// at most n (a multiple of 4, wave-uniform) vector-memory operations still in flight; anything above 60 waits for 60 (waiting for more is safe)
+// wu_dma16b with the same margin (s_nop 2 + s_mov + s_nop 0 = 5 wait states in front of the load)
+__device__ __forceinline__ void dma16(unsigned voff, wu_rsrc_t rsrc, unsigned soff, unsigned lds_byte_addr) {
+    asm volatile("s_nop 2\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_addr) : "memory", "m0");
+}
+// at most n (even, wave-uniform) vector-memory operations still in flight; anything above 62 waits for 62 (waiting for more is safe)
 __device__ __forceinline__ void vm_wait(int n) {
-    switch (n >> 2) {
+    switch (n >> 1) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
-        case 11: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
-        case 13: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
-        case 14: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+        case 21: asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); break;
+        case 22: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+        case 23: asm volatile("s_waitcnt vmcnt(46)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+        case 25: asm volatile("s_waitcnt vmcnt(50)" ::: "memory"); break;
+        case 26: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
+        case 27: asm volatile("s_waitcnt vmcnt(54)" ::: "memory"); break;
+        case 28: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+        case 29: asm volatile("s_waitcnt vmcnt(58)" ::: "memory"); break;
+        case 30: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(62)" ::: "memory"); break;
     }
 }
 }  // namespace pw3
 
-// NW waves: 4 (2 x 2, 64 pixels x 64 couts each) or 8 (4 x 2, 32 pixels x 64 couts each: two waves per SIMD with ONE workgroup per CU, so
-// that the whole LDS can be ring)
-// CONV (round 4): the same pipeline as a 3 x 3 conv, stride 1 or 2 -- K runs over (64-channel chunk, tap), the weight rows of a step are slab `tap` of
-// the [9][Cout][Cin] pack, and its activation rows are GATHERED: row r of the tile is output pixel (n, oy, ox), the DMA lane that fetches it reads input
-// pixel (n, s oy + dy - 1, s ox + dx - 1) or, outside the image, is pushed out of the descriptor's range (zeros).  Every tap re-reads its rows from L2 (no
-// halo reuse): 2.25x the input at stride 2, where it replaces conv3x3_mfma_kernel<T, 2> (one workgroup per CU, register staging: 290-510 TFLOP/s).
-template <int NW, int D, bool HAS_RES, bool HAS_GATE, bool CONV = false>
+// NW waves x TN couts: 8 x 128 (waves 4 x 2, 32 pixels x 64 couts each: two waves per SIMD per workgroup), 4 x 128 (2 x 2, 64 x 64 each), 4 x 64 (4 x 1,
+// 32 x 64 each: the 64-cout layers).
+// CONV (round 4): the same pipeline as a 3 x 3 conv -- K runs over (64-channel chunk, tap of the tile's class), the weight rows of a step are slab
+// `slab` of the [9][Cout][Cin] pack, and its activation rows are GATHERED: row r of the tile is grid pixel (n, oy, ox), the DMA lane that fetches it reads
+// source pixel (n, s oy + dy - 1, s ox + dx - 1) or, outside the image, is pushed out of the descriptor's range (zeros).  Every tap re-reads its rows from
+// L2 (no halo reuse): 2.25x the input at stride 2, where it replaces conv3x3_mfma_kernel<T, 2> (one workgroup per CU, register staging: 290-510 TFLOP/s),
+// and the four parity classes of that conv's data gradient (Args), whose outputs are scattered to their sites by per-lane store offsets.
+template <int NW, int TN, int D, bool HAS_RES, bool HAS_GATE, bool CONV = false>
 __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(const pw3::Args a) {
     using namespace pw3;
-    constexpr int WM = NW == 8 ? 4 : 2, WN = NW / WM, MI = TM / (32 * WM), NI = TN / (32 * WN);
-    static_assert(NI == 2, "the epilogue's instruction offsets assume two 32-cout blocks per wave");
-    constexpr int PA = 16 / NW;          // 1-KiB pieces of each operand per wave and K step
-    constexpr int PD = 2 * PA;           // DMA operations per wave and K step
+    constexpr int WN = TN / 64, WM = NW / WN, MI = TM / (32 * WM), NI = 2;
+    static_assert(TN % 64 == 0 && NW % WN == 0 && MI >= 1 && TM % (32 * WM) == 0, "wave grid");
+    constexpr int kStage = (TM + TN) * kKB;      // activation rows, then weight rows
+    constexpr int PA = TM / 8 / NW;      // 1-KiB pieces of the activation rows per wave and K step
+    constexpr int PW = TN / 8 / NW;      // ... of the weight rows
+    static_assert(PA >= 1 && PW >= 1, "every wave moves at least one piece of each operand");
+    constexpr int PD = PA + PW;          // DMA operations per wave and K step
     constexpr int PS = MI * NI * 2;      // output stores (residual loads, gate loads) per wave and tile
+    static_assert(PD % 2 == 0 && PS % 4 == 0, "vm_wait counts in units of 2");
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bias_lds = (float*)(smem + D * kStage);
@@ -406,7 +441,7 @@ __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(co
     const int G = (int)gridDim.x;
     const int wg = xcd_remap(blockIdx.x, G);
     const int nchunks = a.Cin / 64;
-    const int nk = CONV ? 9 * nchunks : nchunks;
+    const int ncls = CONV ? a.ncls : 1;
 
     for (int i = tid; i < a.Cout; i += NT) bias_lds[i] = a.bias ? a.bias[i] : 0.f;
     __syncthreads();
@@ -416,20 +451,27 @@ __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(co
     //  never dereferenced there -- such lanes are out of the image and pushed out of range)
     const size_t a_shift = CONV ? ((size_t)a.W + 1) * a.ldx * 2 : 0;
     const size_t a_rows = CONV ? (size_t)(a.M / (a.Ho * a.Wo)) * a.H * a.W : (size_t)a.M;
+    const size_t y_rows = CONV ? (size_t)(a.M / (a.Ho * a.Wo)) * a.OH * a.OW : (size_t)a.M;
     const wu_rsrc_t rsA = wu_make_rsrc((const char*)a.x - a_shift, (unsigned)(a_shift + ((a_rows - 1) * a.ldx + a.Cin) * 2));
     const wu_rsrc_t rsW = wu_make_rsrc(a.w, (unsigned)((size_t)(CONV ? 9 : 1) * a.Cout * a.Cin * 2));
-    const wu_rsrc_t rsY = wu_make_rsrc(a.y, (unsigned)((((size_t)a.M - 1) * a.ldy + a.Cout) * 2));
-    const wu_rsrc_t rsR = wu_make_rsrc(HAS_RES ? a.res : a.y, HAS_RES ? (unsigned)((((size_t)a.M - 1) * a.ldres + a.Cout) * 2) : 0u);
-    const wu_rsrc_t rsE = wu_make_rsrc(HAS_GATE ? a.egate : a.y, HAS_GATE ? (unsigned)((((size_t)a.M - 1) * a.ldegate + a.Cout) * 2) : 0u);
-    unsigned voA[PA], voW[PA];
+    const wu_rsrc_t rsY = wu_make_rsrc(a.y, (unsigned)(((y_rows - 1) * a.ldy + a.Cout) * 2));
+    const wu_rsrc_t rsR = wu_make_rsrc(HAS_RES ? a.res : a.y, HAS_RES ? (unsigned)(((y_rows - 1) * a.ldres + a.Cout) * 2) : 0u);
+    const wu_rsrc_t rsE = wu_make_rsrc(HAS_GATE ? a.egate : a.y, HAS_GATE ? (unsigned)(((y_rows - 1) * a.ldegate + a.Cout) * 2) : 0u);
+    unsigned voA[PA], voW[PW];
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
         const int row = 8 * (wave + NW * j) + (lane >> 3);                 // piece wave + NW j holds rows 8 p .. 8 p + 7, lane l lands at + 16 l
         const int sl = (lane & 7) ^ ((row >> 1) & 7);                      // the swizzle of pw_off, applied to the SOURCE slot
         voA[j] = (unsigned)(row * a.ldx * 2 + sl * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const int row = 8 * (wave + NW * j) + (lane >> 3);
+        const int sl = (lane & 7) ^ ((row >> 1) & 7);
         voW[j] = (unsigned)(row * a.Cin * 2 + sl * 16);
     }
     // epilogue: pixel rows 32 MI wm + 32 mi + l31, channels 64 wn + 32 ni + 16 gp + 8 lh (+ 8) -- (ni, gp) travel in the instruction offset
+    // (CONV: recomputed per tile -- the tile's rows are scattered to their output sites, rows without one are pushed out of range)
     unsigned voY[MI], voR[MI], voE[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -440,62 +482,76 @@ __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(co
     }
     const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-    // ---- the two cursors over this workgroup's items (wg, wg + G, ...; cout tile fastest), carried digit by digit ----
-    const int dct = G % a.n_ct, dpt = G / a.n_ct;
-    int f_item = wg, f_ct = wg % a.n_ct, f_pt = wg / a.n_ct, f_k = 0, f_tap = 0;     // (CONV: f_k counts chunks, f_tap the tap inside the chunk)
+    // ---- the two cursors over this workgroup's items (wg, wg + G, ...; digits: class fastest, then cout tile, then pixel tile), carried digit by digit ----
+    struct Cur { int cls, ct, pt; };
+    const int dcl = G % ncls, g1 = G / ncls, dct = g1 % a.n_ct, dpt = g1 / a.n_ct;
+    auto decode = [&](int item) __attribute__((always_inline)) {
+        Cur c; c.cls = item % ncls; const int r = item / ncls; c.ct = r % a.n_ct; c.pt = r / a.n_ct; return c;
+    };
+    auto advance = [&](Cur c) __attribute__((always_inline)) {
+        c.cls += dcl; int cy = c.cls >= ncls ? 1 : 0; c.cls -= cy * ncls;
+        c.ct += dct + cy; cy = c.ct >= a.n_ct ? 1 : 0; c.ct -= cy * a.n_ct;
+        c.pt += dpt + cy;
+        return c;
+    };
+    int f_item = wg, f_k = 0, f_tap = 0;     // (CONV: f_k counts chunks, f_tap the tap inside the chunk)
+    Cur fc = decode(wg);
     bool f_alive = f_item < a.items;
+    int f_ntaps = CONV ? a.cls_ntaps[fc.cls] : 1;
     unsigned baseA[PA], vbits[PA];       // CONV: byte offset of the fetch tile's rows at tap (0, 0) in the shifted descriptor; bit t = tap t is inside the image
-    auto conv_tile = [&](int pt) __attribute__((always_inline)) {
+    auto conv_tile = [&]() __attribute__((always_inline)) {
         const int hw = a.Ho * a.Wo;
+        f_ntaps = a.cls_ntaps[fc.cls];
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             const int row = 8 * (wave + NW * j) + (lane >> 3);
             const int sl = (lane & 7) ^ ((row >> 1) & 7);
-            const int p = pt * TM + row;
+            const int p = fc.pt * TM + row;
             const int n = p / hw, rem = p - n * hw, oy = rem / a.Wo, ox = rem - oy * a.Wo;
             const int iy0 = oy * a.stride, ix0 = ox * a.stride;
             baseA[j] = (unsigned)((((n * a.H + iy0) * a.W + ix0) * a.ldx) * 2 + sl * 16);
             unsigned b = 0;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const bool ok = p < a.M && (unsigned)(iy0 + t / 3 - 1) < (unsigned)a.H && (unsigned)(ix0 + t % 3 - 1) < (unsigned)a.W;
+                const unsigned tw = a.cls_tap[fc.cls][t];
+                const int dy = tw & 3, dx = (tw >> 2) & 3;
+                const bool ok = t < f_ntaps && p < a.M && (unsigned)(iy0 + dy - 1) < (unsigned)a.H && (unsigned)(ix0 + dx - 1) < (unsigned)a.W;
                 b |= (ok ? 1u : 0u) << t;
             }
             vbits[j] = b;
         }
     };
-    if (CONV && f_alive) conv_tile(f_pt);
+    if (CONV && f_alive) conv_tile();
     auto fetch = [&](int stage) __attribute__((always_inline)) {
         const unsigned kill = f_alive ? 0u : kWuOOB;
         const unsigned lds = smem_base + stage * kStage + wave * 1024;
         if constexpr (CONV) {
-            const int dy = f_tap >= 6 ? 2 : (f_tap >= 3 ? 1 : 0), dx = f_tap - 3 * dy;
+            const unsigned tw = a.cls_tap[fc.cls][f_tap];
+            const int dy = tw & 3, dx = (tw >> 2) & 3, slab = tw >> 4;
             const unsigned soA = (unsigned)(((dy * a.W + dx) * a.ldx + f_k * 64) * 2) | kill;
-            const unsigned soW = (unsigned)(((f_tap * a.Cout + f_ct * TN) * a.Cin + f_k * 64) * 2) | kill;
+            const unsigned soW = (unsigned)(((slab * a.Cout + fc.ct * TN) * a.Cin + f_k * 64) * 2) | kill;
 #pragma unroll
             for (int j = 0; j < PA; ++j)
-                wu_dma16b(((vbits[j] >> f_tap) & 1u) ? baseA[j] : kWuOOB, rsA, soA, __builtin_amdgcn_readfirstlane(lds + j * NW * 1024));
+                dma16(((vbits[j] >> f_tap) & 1u) ? baseA[j] : kWuOOB, rsA, soA, __builtin_amdgcn_readfirstlane(lds + j * NW * 1024));
 #pragma unroll
-            for (int j = 0; j < PA; ++j) wu_dma16b(voW[j], rsW, soW, __builtin_amdgcn_readfirstlane(lds + TM * kKB + j * NW * 1024));
-            if (f_alive && ++f_tap == 9) {
+            for (int j = 0; j < PW; ++j) dma16(voW[j], rsW, soW, __builtin_amdgcn_readfirstlane(lds + TM * kKB + j * NW * 1024));
+            if (f_alive && ++f_tap == f_ntaps) {
                 f_tap = 0;
                 if (++f_k == nchunks) {
-                    f_k = 0; f_item += G;
-                    f_ct += dct; const int cy = f_ct >= a.n_ct ? 1 : 0; f_ct -= cy * a.n_ct; f_pt += dpt + cy;
+                    f_k = 0; f_item += G; fc = advance(fc);
                     f_alive = f_item < a.items;
-                    if (f_alive) conv_tile(f_pt);
+                    if (f_alive) conv_tile();
                 }
             }
         } else {
-            const unsigned soA = (unsigned)((f_pt * TM * a.ldx + f_k * 64) * 2) | kill;
-            const unsigned soW = (unsigned)((f_ct * TN * a.Cin + f_k * 64) * 2) | kill;
+            const unsigned soA = (unsigned)((fc.pt * TM * a.ldx + f_k * 64) * 2) | kill;
+            const unsigned soW = (unsigned)((fc.ct * TN * a.Cin + f_k * 64) * 2) | kill;
 #pragma unroll
-            for (int j = 0; j < PA; ++j) wu_dma16b(voA[j], rsA, soA, __builtin_amdgcn_readfirstlane(lds + j * NW * 1024));
+            for (int j = 0; j < PA; ++j) dma16(voA[j], rsA, soA, __builtin_amdgcn_readfirstlane(lds + j * NW * 1024));
 #pragma unroll
-            for (int j = 0; j < PA; ++j) wu_dma16b(voW[j], rsW, soW, __builtin_amdgcn_readfirstlane(lds + TM * kKB + j * NW * 1024));
-            if (f_alive && ++f_k == nk) {
-                f_k = 0; f_item += G;
-                f_ct += dct; const int cy = f_ct >= a.n_ct ? 1 : 0; f_ct -= cy * a.n_ct; f_pt += dpt + cy;
+            for (int j = 0; j < PW; ++j) dma16(voW[j], rsW, soW, __builtin_amdgcn_readfirstlane(lds + TM * kKB + j * NW * 1024));
+            if (f_alive && ++f_k == nchunks) {
+                f_k = 0; f_item += G; fc = advance(fc);
                 f_alive = f_item < a.items;
             }
         }
@@ -513,9 +569,25 @@ __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(co
     constexpr int NRG = PS * ((HAS_RES ? 1 : 0) + (HAS_GATE ? 1 : 0));
     const bool relu = a.act == WU_ACT_RELU;
 
-    int c_ct = wg % a.n_ct, c_pt = wg / a.n_ct;
+    Cur cc = decode(wg);
     for (int c_item = wg; c_item < a.items; c_item += G) {
-        const int m0 = c_pt * TM, co0 = c_ct * TN;
+        const int m0 = cc.pt * TM, co0 = cc.ct * TN;
+        const int nk = CONV ? a.cls_ntaps[cc.cls] * nchunks : nchunks;
+        unsigned soY = (unsigned)((m0 * a.ldy + co0) * 2), soR = (unsigned)((m0 * a.ldres + co0) * 2), soE = (unsigned)((m0 * a.ldegate + co0) * 2);
+        if constexpr (CONV) {            // where this tile's rows land: (n, oy osy + ooy, ox osx + oox) of the OH x OW image, or nowhere
+            const int hw = a.Ho * a.Wo, ooy = a.cls_ooy[cc.cls], oox = a.cls_oox[cc.cls];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int p = m0 + 32 * MI * wm + 32 * mi + l31, c = 64 * wn + 8 * lh;
+                const int n = p / hw, rem = p - n * hw, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                const int py = oy * a.osy + ooy, px = ox * a.osx + oox;
+                const bool ok = p < a.M && py < a.OH && px < a.OW;
+                const int q = (n * a.OH + py) * a.OW + px;
+                voY[mi] = ok ? (unsigned)((q * a.ldy + c) * 2) : kWuOOB;
+                voE[mi] = ok ? (unsigned)((q * a.ldegate + c) * 2) : kWuOOB;
+            }
+            soY = (unsigned)(co0 * 2); soE = soY; soR = soY;
+        }
         f32x16_t acc[MI][NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -533,7 +605,6 @@ __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(co
             __syncthreads();                 // ... for every wave; and every wave has left the stage the DMA below refills
             int pre = 0;
             if (NRG != 0 && k == 0) {        // this tile's residual / gate rows: in flight under its whole K loop
-                const unsigned soR = (unsigned)((m0 * a.ldres + co0) * 2), soE = (unsigned)((m0 * a.ldegate + co0) * 2);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     if constexpr (HAS_RES) {
@@ -584,7 +655,6 @@ __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(co
                 if constexpr (HAS_GATE) asm volatile("" : "+v"(eq[mi][0]), "+v"(eq[mi][1]), "+v"(eq[mi][2]), "+v"(eq[mi][3]));
             }
         }
-        const unsigned soY = (unsigned)((m0 * a.ldy + co0) * 2);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -636,7 +706,7 @@ __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(co
                     else st16<96>(pv, voY[mi], rsY, soY);
                 }
         h_post[0] = PS;
-        c_ct += dct; const int cy = c_ct >= a.n_ct ? 1 : 0; c_ct -= cy * a.n_ct; c_pt += dpt + cy;
+        cc = advance(cc);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the ring's trailing (all-zero) pieces must land before this LDS allocation is released
 }
@@ -1264,35 +1334,83 @@ inline int grid_cap(long long total, int block = 256, int cap = 256 * 16) {
 
 }  // namespace
 
+namespace {
+template <int NW, int TN, bool G>
+void pw3_conv_go(const pw3::Args& p, int grid, hipStream_t s) {
+    constexpr int kSmem = 2 * (pw3::TM + TN) * kKB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv1x1_pw3_kernel<NW, TN, 2, false, G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem + pw3::kMaxCout * 4);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv1x1_pw3_kernel<NW, TN, 2, false, G, true>), dim3((unsigned)grid), dim3(NW * 64), (size_t)kSmem + (size_t)p.Cout * 4, s, p);
+}
+// shared tail of the two launchers below: checks, tile shape (128 couts per tile, or 64 when Cout is an odd multiple of 64), launch
+int pw3_conv_launch(pw3::Args& p, int N, int src_pixels, int out_pixels, int max_out_ld, bool hg, hipStream_t s) {
+    const int pd = g_wu_opt[WU_OPT_PW3] & 7, allow64 = (g_wu_opt[WU_OPT_PW3] >> 4) & 1, min_items = g_wu_opt[WU_OPT_PW3] >> 5;
+    const int tn = p.Cout % 128 == 0 ? 128 : 64;
+    const long long items = (((long long)p.M + pw3::TM - 1) / pw3::TM) * (p.Cout / tn) * p.ncls;
+    // 64-cout tiles (four waves, 128 x 64) are correct but not faster than the register-staged kernels (profiles/r04_s2_gather_bench.txt: SNDisc's first
+    // stride-2 data gradient 80 vs 68 us): off unless option bit 4 asks (tests)
+    if (tn == 64 && !allow64) return 1;
+    if (pd == 0 || p.Cin % 64 != 0 || p.Cout % 64 != 0 || p.Cout > pw3::kMaxCout || items < min_items || items >= (1ll << 30)) return 1;
+    if (((long long)N * src_pixels + p.W + 1 + 2ll * pw3::TM * p.stride * p.stride) * p.ldx * 2 >= (1ll << 31) ||
+        ((long long)N * out_pixels + pw3::TM) * max_out_ld * 2 >= (1ll << 31) || 9ll * p.Cout * p.Cin * 2 >= (1ll << 31)) return 1;
+    if (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.w | (uintptr_t)p.egate) % 16 != 0 || (p.ldx * 2) % 16 != 0 || (p.ldy * 2) % 16 != 0 || (hg && (p.ldegate * 2) % 16 != 0)) return 1;
+    p.n_ct = p.Cout / tn; p.items = (int)items;
+    const int grid = (int)std::min<long long>(items, 2ll * wu_num_cus());
+    if (tn == 128) { if (hg) pw3_conv_go<8, 128, true>(p, grid, s); else pw3_conv_go<8, 128, false>(p, grid, s); }
+    else { if (hg) pw3_conv_go<4, 64, true>(p, grid, s); else pw3_conv_go<4, 64, false>(p, grid, s); }
+    return 0;
+}
+}  // namespace
+
 // 3 x 3 conv (stride 1 or 2, bf16, unmasked) on the persistent LDS-DMA GEMM pipeline with gathered activation rows (conv1x1_pw3_kernel<.., CONV>):
 // 0 = launched, 1 = not applicable (the caller falls back to conv3x3_mfma_kernel).  w_packed: the [9][Cout][Cin] forward pack.
 int conv3x3_gather_launch(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy, const void* egate, int ldegate, int egate_act,
                           int N, int H, int W, int Cin, int Cout, int stride, int act, hipStream_t s) {
-    const int pd = g_wu_opt[WU_OPT_PW3] & 7, min_items = g_wu_opt[WU_OPT_PW3] >> 4;
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-    const long long M = (long long)N * Ho * Wo;
-    const long long items = ((M + pw3::TM - 1) / pw3::TM) * (Cout / pw3::TN);
     const bool hg = egate != nullptr && egate_act != WU_ACT_NONE;
-    if (pd == 0 || Cin % 64 != 0 || Cout % pw3::TN != 0 || Cout > pw3::kMaxCout || items < min_items || items >= (1ll << 30)) return 1;
-    if (((long long)N * H * W + W + 1 + pw3::TM * stride * stride) * ldx * 2 >= (1ll << 31) || (M + pw3::TM) * std::max(ldy, hg ? ldegate : 0) * 2 >= (1ll << 31) ||
-        9ll * Cout * Cin * 2 >= (1ll << 31)) return 1;
-    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w_packed | (uintptr_t)egate) % 16 != 0 || (ldx * 2) % 16 != 0 || (ldy * 2) % 16 != 0 || (hg && (ldegate * 2) % 16 != 0)) return 1;
-    pw3::Args p;
+    pw3::Args p = {};
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.bias = bias; p.res = nullptr; p.egate = (const bf16_t*)egate; p.y = (bf16_t*)y;
     p.ldx = ldx; p.ldres = 0; p.ldegate = hg ? ldegate : 0; p.ldy = ldy;
-    p.M = (int)M; p.Cin = Cin; p.Cout = Cout; p.act = act; p.egate_act = egate_act; p.n_ct = Cout / pw3::TN; p.items = (int)items;
+    p.M = N * Ho * Wo; p.Cin = Cin; p.Cout = Cout; p.act = act; p.egate_act = egate_act;
     p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.stride = stride;
-    const int grid = (int)std::min<long long>(items, 2ll * wu_num_cus());
-    const size_t smem = (size_t)2 * pw3::kStage + (size_t)Cout * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv1x1_pw3_kernel<8, 2, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * pw3::kStage + pw3::kMaxCout * 4);
-        (void)hipFuncSetAttribute((const void*)conv1x1_pw3_kernel<8, 2, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * pw3::kStage + pw3::kMaxCout * 4);
-        attr_set = true;
+    p.ncls = 1; p.cls_ntaps[0] = 9; p.cls_ooy[0] = p.cls_oox[0] = 0;
+    for (int t = 0; t < 9; ++t) p.cls_tap[0][t] = (unsigned)((t / 3) | ((t % 3) << 2) | (t << 4));
+    p.osy = p.osx = 1; p.OH = Ho; p.OW = Wo;
+    if ((long long)N * Ho * Wo >= (1ll << 30)) return 1;
+    return pw3_conv_launch(p, N, H * W, Ho * Wo, std::max(ldy, hg ? ldegate : 0), hg, s);
+}
+
+// Data gradient of a stride-2 3 x 3 conv on the same pipeline: the four parity classes of conv_s2_dgrad_parity_launch (conv3x3_mfma.hip) as ONE launch,
+// class = fastest digit of the item index.  dy: (N, Cout, Ho, Wo) pre-gated; w_dgrad: the rotated pack [tap'][Cin][Cout]; dx: (N, Cin, H, W), optionally
+// multiplied by act'(egate).  0 = launched, 1 = not applicable.
+int conv_s2_dgrad_gather_launch(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx, const void* egate, int ldegate, int egate_act,
+                                int N, int H, int W, int Cin, int Cout, hipStream_t s) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const bool hg = egate != nullptr && egate_act != WU_ACT_NONE;
+    pw3::Args p = {};
+    p.x = (const bf16_t*)dy; p.w = (const bf16_t*)w_dgrad; p.bias = nullptr; p.res = nullptr; p.egate = (const bf16_t*)egate; p.y = (bf16_t*)dx;
+    p.ldx = lddy; p.ldres = 0; p.ldegate = hg ? ldegate : 0; p.ldy = lddx;
+    p.M = N * Ho * Wo; p.Cin = Cout; p.Cout = Cin;       // the GEMM's K = the forward conv's output channels, its N = the forward conv's input channels
+    p.act = WU_ACT_NONE; p.egate_act = egate_act;
+    p.H = Ho; p.W = Wo; p.Ho = Ho; p.Wo = Wo; p.stride = 1;
+    p.ncls = 4; p.osy = p.osx = 2; p.OH = H; p.OW = W;
+    for (int c = 0; c < 4; ++c) {
+        const int pp = c < 2 ? 1 : 0, q = (c == 0 || c == 2) ? 1 : 0;
+        // forward taps reaching input parity p: kh = 1 from output row i (source row offset dy = 1); kh = 0 from row i + 1 (dy = 2), kh = 2 from row i
+        const int nk_y = pp ? 2 : 1, nk_x = q ? 2 : 1;
+        const int khs[2] = {pp ? 0 : 1, 2}, dys[2] = {pp ? 2 : 1, 1};
+        const int kws[2] = {q ? 0 : 1, 2}, dxs[2] = {q ? 2 : 1, 1};
+        p.cls_ntaps[c] = nk_y * nk_x;
+        for (int iy = 0; iy < nk_y; ++iy)
+            for (int ix = 0; ix < nk_x; ++ix)
+                p.cls_tap[c][iy * nk_x + ix] = (unsigned)(dys[iy] | (dxs[ix] << 2) | ((8 - (khs[iy] * 3 + kws[ix])) << 4));   // rotated pack: forward tap (kh, kw) in slab 8 - (3 kh + kw)
+        p.cls_ooy[c] = pp; p.cls_oox[c] = q;
     }
-    if (hg) hipLaunchKernelGGL((conv1x1_pw3_kernel<8, 2, false, true, true>), dim3((unsigned)grid), dim3(512), smem, s, p);
-    else hipLaunchKernelGGL((conv1x1_pw3_kernel<8, 2, false, false, true>), dim3((unsigned)grid), dim3(512), smem, s, p);
-    return 0;
+    if ((long long)N * Ho * Wo >= (1ll << 30)) return 1;
+    return pw3_conv_launch(p, N, Ho * Wo, H * W, std::max(lddx, hg ? ldegate : 0), hg, s);
 }
 
 #define DISPATCH_T(dtype, ...)                                      \
@@ -1337,36 +1455,40 @@ extern "C" int wu_conv1x1_fwd(const void* x, int ldx, const void* w, const float
     hipStream_t s = (hipStream_t)stream;
     wu_prof_pre(WU_FAM_CONV1X1, s);
     // Round 4: the persistent LDS-DMA form (128 x 128 tiles) where it applies.  Option 15: low 3 bits = ring depth D (0 = off), bit 3 = eight waves per workgroup instead
-    // of four (D = 2: two workgroups per CU; else one), the rest = the least number of tiles (below it the 64 x 64 tiles fill more of the chip)
+    // of four (D = 2: two workgroups per CU; else one), bit 4 = 64-cout tiles allowed where Cout % 128 != 0, bits 5.. = the least number of tiles (below it the 64 x 64 tiles fill more of the chip)
     {
-        const int pd = g_wu_opt[WU_OPT_PW3] & 7, pw8 = (g_wu_opt[WU_OPT_PW3] >> 3) & 1, min_items = g_wu_opt[WU_OPT_PW3] >> 4;
-        const long long items = ((a.M + pw3::TM - 1) / pw3::TM) * (Cout / pw3::TN);
+        const int pd = g_wu_opt[WU_OPT_PW3] & 7, pw8 = (g_wu_opt[WU_OPT_PW3] >> 3) & 1, allow64 = (g_wu_opt[WU_OPT_PW3] >> 4) & 1, min_items = g_wu_opt[WU_OPT_PW3] >> 5;
+        const int tn = Cout % 128 == 0 ? 128 : 64;           // 64-cout tiles (four waves) for the layers whose Cout is an odd multiple of 64: option bit 4
+        const long long items = ((a.M + pw3::TM - 1) / pw3::TM) * (Cout / tn);
         const long long max_ld = std::max(std::max(ldx, ldy), std::max(residual ? ldres : 0, egate ? ldegate : 0));
-        if (pd >= 2 && pd <= 4 && dtype == WU_BF16 && in_stride == 1 && out_stride == 1 && Cout % pw3::TN == 0 && Cout <= pw3::kMaxCout &&
+        if (pd >= 2 && pd <= 4 && (tn == 128 || allow64) && dtype == WU_BF16 && in_stride == 1 && out_stride == 1 && Cout <= pw3::kMaxCout &&
             items >= min_items && items < (1ll << 30) && (a.M + pw3::TM) * max_ld * 2 < (1ll << 31) && (long long)Cout * Cin * 2 < (1ll << 31)) {
-            pw3::Args p;
+            pw3::Args p = {};
             p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.res = (const bf16_t*)residual; p.egate = (const bf16_t*)egate; p.y = (bf16_t*)y;
             p.ldx = ldx; p.ldres = residual ? ldres : 0; p.ldegate = egate ? ldegate : 0; p.ldy = ldy;
-            p.M = (int)a.M; p.Cin = Cin; p.Cout = Cout; p.act = act; p.egate_act = egate_act; p.n_ct = Cout / pw3::TN; p.items = (int)items;
-            const int per_cu = pd == 2 ? 2 : 1;
+            p.M = (int)a.M; p.Cin = Cin; p.Cout = Cout; p.act = act; p.egate_act = egate_act; p.n_ct = Cout / tn; p.items = (int)items;
+            p.ncls = 1;
+            const int dd = tn == 64 ? 2 : pd;                // (the 64-cout form has one configuration: four waves, D = 2)
+            const int per_cu = dd == 2 ? 2 : 1;
             const int grid3 = (int)std::min<long long>(items, (long long)per_cu * wu_num_cus());
-            const size_t smem3 = (size_t)pd * pw3::kStage + (size_t)Cout * 4;
+            const size_t smem3 = (size_t)dd * (pw3::TM + tn) * kKB + (size_t)Cout * 4;
             const bool hr = residual != nullptr, hg = egate != nullptr && egate_act != WU_ACT_NONE;
-#define WU_PW3_GO(NW_, D_, R_, G_)                                                                                                      \
+#define WU_PW3_GO(NW_, TN_, D_, R_, G_)                                                                                                  \
             do {                                                                                                                         \
                 static bool attr3 = false;                                                                                               \
-                if (!attr3) { (void)hipFuncSetAttribute((const void*)conv1x1_pw3_kernel<NW_, D_, R_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, D_ * pw3::kStage + pw3::kMaxCout * 4); attr3 = true; } \
-                hipLaunchKernelGGL((conv1x1_pw3_kernel<NW_, D_, R_, G_>), dim3((unsigned)grid3), dim3(NW_ * 64), smem3, s, p);         \
+                if (!attr3) { (void)hipFuncSetAttribute((const void*)conv1x1_pw3_kernel<NW_, TN_, D_, R_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, D_ * (pw3::TM + TN_) * kKB + pw3::kMaxCout * 4); attr3 = true; } \
+                hipLaunchKernelGGL((conv1x1_pw3_kernel<NW_, TN_, D_, R_, G_>), dim3((unsigned)grid3), dim3(NW_ * 64), smem3, s, p);    \
             } while (0)
-#define WU_PW3_D(NW_, D_)                                                        \
-            do {                                                                 \
-                if (hr && hg) WU_PW3_GO(NW_, D_, true, true);                    \
-                else if (hr) WU_PW3_GO(NW_, D_, true, false);                    \
-                else if (hg) WU_PW3_GO(NW_, D_, false, true);                    \
-                else WU_PW3_GO(NW_, D_, false, false);                           \
+#define WU_PW3_D(NW_, TN_, D_)                                                        \
+            do {                                                                      \
+                if (hr && hg) WU_PW3_GO(NW_, TN_, D_, true, true);                    \
+                else if (hr) WU_PW3_GO(NW_, TN_, D_, true, false);                    \
+                else if (hg) WU_PW3_GO(NW_, TN_, D_, false, true);                    \
+                else WU_PW3_GO(NW_, TN_, D_, false, false);                           \
             } while (0)
-            if (pw8) { if (pd == 2) WU_PW3_D(8, 2); else if (pd == 3) WU_PW3_D(8, 3); else WU_PW3_D(8, 4); }
-            else { if (pd == 2) WU_PW3_D(4, 2); else if (pd == 3) WU_PW3_D(4, 3); else WU_PW3_D(4, 4); }
+            if (tn == 64) WU_PW3_D(4, 64, 2);
+            else if (pw8) { if (pd == 2) WU_PW3_D(8, 128, 2); else if (pd == 3) WU_PW3_D(8, 128, 3); else WU_PW3_D(8, 128, 4); }
+            else { if (pd == 2) WU_PW3_D(4, 128, 2); else if (pd == 3) WU_PW3_D(4, 128, 3); else WU_PW3_D(4, 128, 4); }
 #undef WU_PW3_D
 #undef WU_PW3_GO
             wu_prof_post(WU_FAM_CONV1X1, s, 2.0 * (double)a.M * Cin * Cout, ((double)a.M * (Cin + Cout * (residual ? 2 : 1)) + (double)Cin * Cout) * esz);
