@@ -57,7 +57,11 @@ int wu_cu_count(void);
  *   11: Cin = 64 / one-cout-tile convs keep both weight chunks resident in LDS across a workgroup's tiles (default 1)
  *   12: pointwise-GEMM pixel tile (0 = 64 rows (default), 1 = 256 rows, 2 = 128 rows)
  *   13: image-layout 3 -> 3 conv (SNDisc's first layer): 1 = LDS-tiled kernels (default), 0 = one thread per pixel
- *   14: stride-2 data gradient: 1 = four parity-class sparse-tap convs in one launch (default), 0 = zero-stuffed dY + stride-1 conv */
+ *   14: stride-2 data gradient: 1 = four parity-class sparse-tap convs in one launch (default), 0 = zero-stuffed dY + stride-1 conv
+ *   15: persistent LDS-DMA GEMM pipeline (round 4: pointwise convs with 128 x 128 / 128 x 64 tiles; stride-2 3x3 convs and the parity classes of
+ *       their data gradient with gathered rows).  Bits 0-2 = ring depth D (0 = off: the register-staged kernels everywhere), bit 3 = eight waves
+ *       per workgroup (else four), bit 4 = 64-cout tiles also for the 3x3 forms, bits 5.. = the least number of tiles that takes this path.
+ *       Default 2 + 8 + (128 << 5): D = 2, eight waves, two workgroups per CU, from 128 tiles. */
 int wu_set_option(int key, int value);
 /* Diagnostic: device buffer of 256*8*8 uint64 receiving per-wave phase cycle sums of the persistent conv / wgrad kernels
  * (DMA wait, compute, whole-kernel s_memtime and s_memrealtime deltas -> in-kernel clock, barrier, epilogue, tiles, chunks);

@@ -396,6 +396,8 @@ extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, cons
     }
     wu_prof_pre(fam, s);
     // Round 4: stride 2 goes to the gathered-row form of the persistent LDS-DMA GEMM (option 15; resnet.hip) where its shape allows
+    // (stride 1 on small images was measured too: 256 -> 256 @16x16 26.6 us against 24.1 on the register-staged kernel -- nine L2 reads of every row
+    //  against a halo in LDS -- and 512 -> 512 @8x8 48 against 68 only from batch 64: not taken)
     if (dtype == WU_BF16 && !m && stride == 2 && (g_wu_opt[WU_OPT_PW3] & 7) &&
         conv3x3_gather_launch(x, ldx, w_packed, bias, y, ldy, egate, ldegate, egate_act, N, H, W, Cin, Cout, stride, act, s) == 0) {
         const double pix = (double)N * a.Ho * a.Wo;
