@@ -103,3 +103,46 @@ def test_library_has_no_packed_fp32_valu_ops(tmp_path):
     bad = [l.strip() for l in text.splitlines() if re.search(r"\bv_pk_(fma|mul|add)_f32\b", l)]
     assert not bad, f"{len(bad)} packed-FP32 VALU instructions in the shipped library, e.g. {bad[:3]}"
     assert "v_mfma_f32_32x32x16_bf16" in text and "buffer_load_dwordx4" in text      # sanity: this IS the device code
+
+
+@pytest.mark.skipif(not (os.path.exists(OBJDUMP) and os.path.exists(LIB)), reason="needs llvm-objdump and the built library")
+def test_no_vmem_instruction_reads_an_sgpr_a_valu_has_just_written(tmp_path):
+    """A vector-memory instruction may not read an SGPR (descriptor word, scalar offset) within 5 wait states of a VALU instruction that wrote
+    it (v_readlane_b32 / v_readfirstlane_b32).  The compiler pads its own VMEM instructions; it does NOT see into inline asm, and it restores
+    spilled SGPRs with v_readlane_b32 right in front of the instruction that needs them -- round 4's gathered-row data-gradient instance read a
+    half-restored descriptor in the first load of a group (gate of channels 0-15 wrong, 16-63 right).  The asm blocks of the LDS-DMA kernels carry
+    their own s_nop since; this checks every VMEM instruction of the machine code that ships, along straight-line code."""
+    from wu import _build
+    assert not _build.is_stale(), "libwu_kernels.so was not built from the sources in the tree (run __graft_entry__.build())"
+    _, text = _device_disassembly(tmp_path)
+    vmem = re.compile(r"^(buffer_|global_|flat_|scratch_|tbuffer_)")
+    sreg = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]")
+    age = {}                # sgpr index -> wait states since a VALU wrote it
+    bad, n_vmem = [], 0
+    for line in text.splitlines():
+        m = re.match(r"^\s+([a-z_0-9]+)\s*(.*?)\s*//", line)
+        if not m:
+            if line.rstrip().endswith(":"):        # a label: another path may arrive here -- keep the fall-through history (the tighter one)
+                continue
+            continue
+        op, args = m.group(1), m.group(2)
+        if vmem.match(op):
+            n_vmem += 1
+            for r in sreg.finditer(args):
+                regs = [int(r.group(1))] if r.group(1) else list(range(int(r.group(2)), int(r.group(3)) + 1))
+                for x in regs:
+                    if age.get(x, 99) < 5:
+                        bad.append((line.strip(), x, age[x]))
+        step = int(args.split()[0], 0) + 1 if op == "s_nop" else 1
+        for x in list(age):
+            age[x] += step
+            if age[x] > 8:
+                del age[x]
+        if op in ("v_readlane_b32", "v_readfirstlane_b32"):
+            d = re.match(r"s(\d+)", args)
+            if d:
+                age[int(d.group(1))] = 0
+        if op == "s_endpgm":
+            age.clear()
+    assert n_vmem > 1000
+    assert not bad, f"{len(bad)} VMEM instructions read a freshly VALU-written SGPR, e.g. {bad[:3]}"
