@@ -360,18 +360,24 @@ struct Args {
 // compiler has just restored from a spill lane with v_readlane_b32 -- it does in the register-hungry instances -- must be 5 wait states old before
 // a VMEM instruction reads it ("VALU writes SGPR -> VMEM reads that SGPR"; seen as a wrong first load of a group, the later ones correct), and the
 // data registers of a 128-bit store may not be rewritten in the next cycle.  Every block therefore carries its own s_nop.
-template <int OFF> __device__ __forceinline__ u32x4_t ld16(unsigned voff, wu_rsrc_t rs, unsigned soff) {
+// PAD: the block carries its own 5 wait states (the CONV instances, where descriptors do get spilled); the pointwise instances keep every descriptor
+// in SGPRs and go without -- tests/test_isa_cpu.py checks the shipped machine code for the hazard either way.
+template <int OFF, bool PAD> __device__ __forceinline__ u32x4_t ld16(unsigned voff, wu_rsrc_t rs, unsigned soff) {
     u32x4_t v;
-    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
+    if constexpr (PAD) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
+    else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
     return v;
 }
-template <int OFF> __device__ __forceinline__ void st16(u32x4_t v, unsigned voff, wu_rsrc_t rs, unsigned soff) {
-    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
+template <int OFF, bool PAD> __device__ __forceinline__ void st16(u32x4_t v, unsigned voff, wu_rsrc_t rs, unsigned soff) {
+    if constexpr (PAD) asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
+    else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
 }
-// wu_dma16b with the same margin (s_nop 2 + s_mov + s_nop 0 = 5 wait states in front of the load)
-__device__ __forceinline__ void dma16(unsigned voff, wu_rsrc_t rsrc, unsigned soff, unsigned lds_byte_addr) {
-    asm volatile("s_nop 2\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_addr) : "memory", "m0");
+// wu_dma16b, optionally with the same margin (s_nop 2 + s_mov + s_nop 0 = 5 wait states in front of the load)
+template <bool PAD> __device__ __forceinline__ void dma16(unsigned voff, wu_rsrc_t rsrc, unsigned soff, unsigned lds_byte_addr) {
+    if constexpr (PAD) asm volatile("s_nop 2\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                                    :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_addr) : "memory", "m0");
+    else asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                      :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_addr) : "memory", "m0");
 }
 // at most n (even, wave-uniform) vector-memory operations still in flight; anything above 62 waits for 62 (waiting for more is safe)
 __device__ __forceinline__ void vm_wait(int n) {
@@ -532,9 +538,9 @@ __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(co
             const unsigned soW = (unsigned)(((slab * a.Cout + fc.ct * TN) * a.Cin + f_k * 64) * 2) | kill;
 #pragma unroll
             for (int j = 0; j < PA; ++j)
-                dma16(((vbits[j] >> f_tap) & 1u) ? baseA[j] : kWuOOB, rsA, soA, __builtin_amdgcn_readfirstlane(lds + j * NW * 1024));
+                dma16<CONV>(((vbits[j] >> f_tap) & 1u) ? baseA[j] : kWuOOB, rsA, soA, __builtin_amdgcn_readfirstlane(lds + j * NW * 1024));
 #pragma unroll
-            for (int j = 0; j < PW; ++j) dma16(voW[j], rsW, soW, __builtin_amdgcn_readfirstlane(lds + TM * kKB + j * NW * 1024));
+            for (int j = 0; j < PW; ++j) dma16<CONV>(voW[j], rsW, soW, __builtin_amdgcn_readfirstlane(lds + TM * kKB + j * NW * 1024));
             if (f_alive && ++f_tap == f_ntaps) {
                 f_tap = 0;
                 if (++f_k == nchunks) {
@@ -547,9 +553,9 @@ __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(co
             const unsigned soA = (unsigned)((fc.pt * TM * a.ldx + f_k * 64) * 2) | kill;
             const unsigned soW = (unsigned)((fc.ct * TN * a.Cin + f_k * 64) * 2) | kill;
 #pragma unroll
-            for (int j = 0; j < PA; ++j) dma16(voA[j], rsA, soA, __builtin_amdgcn_readfirstlane(lds + j * NW * 1024));
+            for (int j = 0; j < PA; ++j) dma16<CONV>(voA[j], rsA, soA, __builtin_amdgcn_readfirstlane(lds + j * NW * 1024));
 #pragma unroll
-            for (int j = 0; j < PW; ++j) dma16(voW[j], rsW, soW, __builtin_amdgcn_readfirstlane(lds + TM * kKB + j * NW * 1024));
+            for (int j = 0; j < PW; ++j) dma16<CONV>(voW[j], rsW, soW, __builtin_amdgcn_readfirstlane(lds + TM * kKB + j * NW * 1024));
             if (f_alive && ++f_k == nchunks) {
                 f_k = 0; f_item += G; fc = advance(fc);
                 f_alive = f_item < a.items;
@@ -608,12 +614,12 @@ __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(co
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     if constexpr (HAS_RES) {
-                        rq[mi][0] = ld16<0>(voR[mi], rsR, soR); rq[mi][1] = ld16<32>(voR[mi], rsR, soR);
-                        rq[mi][2] = ld16<64>(voR[mi], rsR, soR); rq[mi][3] = ld16<96>(voR[mi], rsR, soR);
+                        rq[mi][0] = ld16<0, CONV>(voR[mi], rsR, soR); rq[mi][1] = ld16<32, CONV>(voR[mi], rsR, soR);
+                        rq[mi][2] = ld16<64, CONV>(voR[mi], rsR, soR); rq[mi][3] = ld16<96, CONV>(voR[mi], rsR, soR);
                     }
                     if constexpr (HAS_GATE) {
-                        eq[mi][0] = ld16<0>(voE[mi], rsE, soE); eq[mi][1] = ld16<32>(voE[mi], rsE, soE);
-                        eq[mi][2] = ld16<64>(voE[mi], rsE, soE); eq[mi][3] = ld16<96>(voE[mi], rsE, soE);
+                        eq[mi][0] = ld16<0, CONV>(voE[mi], rsE, soE); eq[mi][1] = ld16<32, CONV>(voE[mi], rsE, soE);
+                        eq[mi][2] = ld16<64, CONV>(voE[mi], rsE, soE); eq[mi][3] = ld16<96, CONV>(voE[mi], rsE, soE);
                     }
                 }
                 pre = NRG;
@@ -700,10 +706,10 @@ __global__ __launch_bounds__(NW * 64, D == 2 ? 2 : 1) void conv1x1_pw3_kernel(co
                     }
                     const uint4 pk = pack16<bf16_t>(o);
                     u32x4_t pv; pv.x = pk.x; pv.y = pk.y; pv.z = pk.z; pv.w = pk.w;
-                    if (ni == 0 && gp == 0) st16<0>(pv, voY[mi], rsY, soY);
-                    else if (ni == 0) st16<32>(pv, voY[mi], rsY, soY);
-                    else if (gp == 0) st16<64>(pv, voY[mi], rsY, soY);
-                    else st16<96>(pv, voY[mi], rsY, soY);
+                    if (ni == 0 && gp == 0) st16<0, CONV>(pv, voY[mi], rsY, soY);
+                    else if (ni == 0) st16<32, CONV>(pv, voY[mi], rsY, soY);
+                    else if (gp == 0) st16<64, CONV>(pv, voY[mi], rsY, soY);
+                    else st16<96, CONV>(pv, voY[mi], rsY, soY);
                 }
         h_post[0] = PS;
         cc = advance(cc);
