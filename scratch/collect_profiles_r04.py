@@ -5,7 +5,8 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
 for a, b in (("r04_pmc.json", "r04_pmc.json"), ("r04_pmc.md", "r04_pmc.md"), ("r04_layer_table.md", "r04_layer_table.md"),
              ("prof_r04final/r04final_kernel_stats.csv", "r04_bench_b32_bf16_kernel_stats.csv"), ("r04_bench_default.json", "r04_bench_default.json"),
-             ("r04_gan_phase_times.txt", "r04_gan_phase_times.txt"), ("r04_s2_bench.txt", "r04_s2_bench.txt")):
+             ("r04_gan_phase_times.txt", "r04_gan_phase_times.txt"), ("r04_s2_bench.txt", "r04_s2_bench.txt"),
+             ("r04_gan_cls_kernel_table.txt", "r04_gan_cls_kernel_table.txt"), ("r04_gan_est_kernel_table.txt", "r04_gan_est_kernel_table.txt")):
     if os.path.exists(os.path.join(G, a)):
         shutil.copy(os.path.join(G, a), os.path.join(P, b))
 with open(os.path.join(P, "r04_other_workloads.jsonl"), "w") as fh:

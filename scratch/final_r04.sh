@@ -19,4 +19,9 @@ timeout -k 10 300 python bench.py --fwd-only --graph --dropout-active --batch 16
 echo "infer done"
 timeout -k 10 200 python scratch/gan_phase_time.py cls 32 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_gan_phase_times.txt || exit 1
 timeout -k 10 200 python scratch/bench_s2.py 32 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_s2_bench.txt || exit 1
-echo "gan phases / stride-2 done"
+timeout -k 10 300 python scratch/bench_s2_graph.py 32 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_s2_gather_bench_final.txt || exit 1
+timeout -k 10 300 python scratch/pw_vs_blas.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_pw3_bench_final.txt || exit 1
+echo "gan phases / stride-2 / pointwise done"
+scratch/prof_gan_kernels.sh gan-cls 32 gankf > gpurun_out/r04_gan_cls_kernel_table.txt 2>&1 || exit 1
+scratch/prof_gan_kernels.sh gan-est 64 gankg > gpurun_out/r04_gan_est_kernel_table.txt 2>&1 || exit 1
+echo "gan kernel tables done"

@@ -18,7 +18,9 @@ FAM_CONV_FWD, FAM_WGRAD, FAM_CONV_DGRAD, FAM_CONV_S2, FAM_WGRAD_S2, FAM_CONV1X1 
 FAMILY_KERNEL = {1: "conv3x3_mfma_v2_kernel (forward + data-gradient convs; generic conv3x3_mfma_kernel for fp32 / narrow images)",
                  2: "conv3x3_wgrad_v2_kernel (generic conv3x3_wgrad_kernel for fp32 / narrow images)",
                  3: "conv3x3_mfma_kernel<T,1,true> (in-kernel gated dgrad; unused by the fused graph)",
-                 4: "conv3x3_mfma_kernel<T,2,false>", 5: "conv3x3_wgrad_kernel<T,2>", 6: "conv1x1_mfma_kernel<T> (estimator)"}
+                 4: "stride-2 3x3 conv forward + data gradient: conv1x1_pw3_kernel<.., CONV> (gathered rows); conv3x3_mfma_kernel<T,2,false> / tap-list classes for 64-cout and fp32",
+                 5: "conv3x3_wgrad_kernel<T,2>",
+                 6: "pointwise convs (estimator): conv1x1_pw3_kernel; conv1x1_mfma_kernel<T> for strided / small / fp32"}
 
 P, I, F, U64, SZ = c_void_p, c_int, c_float, c_uint64, c_size_t
 
