@@ -285,6 +285,22 @@ def main():
                 iso = {f: _lib.prof_query(f) for f in families}
                 _lib.prof_end()
                 UG.SIDE_STREAM_WGRAD = True
+        # GAN workloads: the passes of an iteration overlap on several streams (D beside G / the estimator, weight gradients beside data
+        # gradients), so a launch's event pair above also spans the time it shares the chip or waits behind another stream's kernels.
+        # One more untimed iteration with every overlap switched OFF gives each family's rate when its kernels run one at a time.
+        seq = None
+        if gan is not None and world == 1:
+            from wu import unet_graph as UG, train_step as TS
+            saved = (UG.SIDE_STREAM_WGRAD, TS.OVERLAP_D_WITH_ESTIMATOR, TS.OVERLAP_D_PASSES)
+            UG.SIDE_STREAM_WGRAD, TS.OVERLAP_D_WITH_ESTIMATOR, TS.OVERLAP_D_PASSES = False, False, False
+            try:
+                step(); torch.cuda.synchronize()
+                _lib.prof_begin(families, 1024 + 64)
+                step(); torch.cuda.synchronize()
+                seq = {f: _lib.prof_query(f) for f in families}
+                _lib.prof_end()
+            finally:
+                UG.SIDE_STREAM_WGRAD, TS.OVERLAP_D_WITH_ESTIMATOR, TS.OVERLAP_D_PASSES = saved
         dom = max(stats, key=lambda f: stats[f]["ms"])
         s = stats[dom]
         peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
@@ -330,6 +346,15 @@ def main():
                                                                       "frac_of_8TBps": round(stats[f]["bytes"] / max(stats[f]["ms"], 1e-9) / 1e6 / 8000.0, 4)}
                                                                      if f == _lib.FAM_CONV1X1 else {}))
                                       for f in families}}
+            if seq is not None:
+                roof["other_kernels_sequential"] = dict(
+                    {"note": "one untimed iteration with every overlap off (one stream): each launch's event pair spans that launch alone (+ ~5 us of event records)"},
+                    **{_lib.FAMILY_KERNEL[f]: dict({"ms_per_step": round(seq[f]["ms"], 3), "launches_per_step": seq[f]["launches"],
+                                                    "TFLOP/s": round(seq[f]["flops"] / max(seq[f]["ms"], 1e-9) / 1e9, 1)},
+                                                   **({"GB/s": round(seq[f]["bytes"] / max(seq[f]["ms"], 1e-9) / 1e6, 1),
+                                                       "frac_of_8TBps": round(seq[f]["bytes"] / max(seq[f]["ms"], 1e-9) / 1e6 / 8000.0, 4)}
+                                                      if f == _lib.FAM_CONV1X1 else {}))
+                       for f in families if seq[f]["launches"]})
 
     if rank == 0:
         imgs = a.batch * world * a.steps
