@@ -158,6 +158,15 @@ int wu_conv3x3_relu_pool_fwd(const void* x, int ldx, const void* w_packed, const
 int wu_conv3x3_relu_pool_bits_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                                   void* pool, int ldpool, void* gate_bits_out, void* sel_bits_out,
                                   int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+/* The last decoder conv AND the network's head in one launch (round 4; cunet.py:78-82: dconv_up1[2] + ReLU, then tanh(conv_last(y))):
+ * y = ReLU(conv3x3(x) + bias) as above and out_nchw[N][3][H][W] (fp32) = tanh(head_w[3][64] . y + head_bias), the head computed on the matrix
+ * cores from the conv epilogue's packed registers (head weights split into three bf16 terms: fp32-exact products of the STORED
+ * bf16 y).  y == NULL: the 64-channel tensor is not written at all (inference; ldy ignored).  bf16 LDS-DMA path only, Cout == 64,
+ * 64 <= Cin < 256, Cin % 32 == 0: ask wu_conv3x3_relu_head_supported (1 = yes); otherwise call wu_conv3x3_fwd + wu_conv1x1_tanh_fwd. */
+int wu_conv3x3_relu_head_supported(int H, int W, int ldx, int ldy, int Cin, int Cout, int dtype);
+int wu_conv3x3_relu_head_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                             const float* head_w, const float* head_bias, float* out_nchw,
+                             int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
 int wu_maxpool2_bwd_bits(const unsigned* gate_bits, const unsigned* sel_bits, const void* dy, int lddy, const void* dskip, int lddskip,
                          void* dx, int lddx, int N, int H, int W, int C, int dtype, void* stream);
 

@@ -468,3 +468,82 @@ def test_stride2_conv_on_the_gathered_row_pipeline(shape):
     finally:
         _lib.call("wu_set_option", OPT_PW3, DEFAULT)
         _lib.call("wu_set_option", OPT_GRID, 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# last decoder conv + 1x1 head + tanh in ONE launch (csrc/conv3x3_mfma_v2.hip GATED = 5; cunet.py:78-82)
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [
+    (2, 64, 64, 64),       # the network's own form (64 -> 64, weights resident in LDS), interior tiles only
+    (3, 64, 40, 48),       # ragged: a half-empty bottom tile row and a half-empty right tile column
+    (1, 192, 32, 96),      # six K chunks per tile (weights re-fetched), three column tiles
+    (33, 64, 32, 32),      # more tiles than one pass of a small grid: the deferred stores of several tiles per workgroup
+])
+def test_conv_relu_head_fused_vs_two_launches(shape):
+    """y must be BIT-IDENTICAL to the plain conv's (same K loop, same epilogue); the head agrees with the stand-alone fp32 head kernel on the
+    same stored bf16 y to fp32 rounding (its weights enter the MFMA as bf16 high part + bf16 residual, products exact in fp32; only the
+    summation order differs), and with a float64 evaluation of tanh(W y + b); without y the image is the same bit for bit."""
+    from wu import _lib, kernels as K
+    from wu.layout import as_nhwc, empty_nhwc
+    n, cin, h, w = shape
+    dev = _dev()
+    bf = torch.bfloat16
+    x = as_nhwc(_rand((n, cin, h, w), 11, -1, 2).to(dev), _lib.BF16)
+    wt = (_rand((64, cin, 3, 3), 12) * (2.0 / (9 * cin)) ** 0.5 * 1.7).to(dev)
+    bias = _rand((64,), 13, -0.2, 0.2).to(dev)
+    hw_ = (_rand((3, 64), 14) * 0.35).to(dev)
+    hb = _rand((3,), 15, -0.3, 0.3).to(dev)
+    assert K.conv3x3_head_supported(x)
+    wf, _ = K.pack_conv3x3(wt, _lib.BF16)
+    y_ref = K.conv3x3(x, wf, bias, empty_nhwc(n, 64, h, w, bf, dev), 1, K.ACT_RELU)
+    out_ref = K.conv1x1_tanh(y_ref, hw_, hb, torch.empty((n, 3, h, w), device=dev))
+    y = torch.full((n, h, w, 64), float("nan"), dtype=bf, device=dev).permute(0, 3, 1, 2)
+    out = torch.full((n, 3, h, w), float("nan"), device=dev)
+    K.conv3x3_relu_head(x, wf, bias, y, hw_, hb, out)
+    out2 = torch.full((n, 3, h, w), float("nan"), device=dev)
+    K.conv3x3_relu_head(x, wf, bias, None, hw_, hb, out2)
+    torch.cuda.synchronize()
+    assert torch.equal(y.float(), y_ref.float())
+    assert not torch.isnan(out).any()
+    z = torch.einsum("kc,nchw->nkhw", hw_.double().cpu(), y_ref.double().cpu()) + hb.double().cpu().view(1, 3, 1, 1)
+    want = torch.tanh(z)
+    assert (out.double().cpu() - want).abs().max().item() < 2e-6
+    assert (out - out_ref).abs().max().item() < 2e-6
+    assert torch.equal(out, out2)
+
+
+def test_unet_forward_with_and_without_the_fused_head():
+    """The whole generator, training mode (same dropout seed) and eval mode: outputs within fp32 rounding of the two-launch path and every
+    gradient within fp32 rounding too (the backward is the same kernels on a bit-identical y and an image that differs by ~1e-7)."""
+    import cunet
+    from wu import unet_graph as UG
+    dev = _dev()
+    torch.manual_seed(3)
+    net = cunet.Conditional_UNet(5, precision="bf16").to(dev)
+    x = _rand((2, 3, 64, 96), 21).to(dev)
+    c = torch.eye(5)[[1, 3]].to(dev)
+    res = {}
+    try:
+        for fused in (True, False):
+            UG.HEAD_FUSED = fused
+            net.train()
+            net.dropout_seed = 5
+            net.zero_grad(set_to_none=True)
+            xg = x.clone().requires_grad_(True)
+            out = net(xg, c)
+            (out - x).abs().mean().backward()
+            grads = [p.grad.clone() for p in net.parameters() if p.grad is not None] + [xg.grad.clone()]
+            assert len(grads) >= 37
+            net.eval()
+            with torch.no_grad():
+                oe = net(x, c)
+            torch.cuda.synchronize()
+            res[fused] = (out.detach().clone(), grads, oe.clone())
+    finally:
+        UG.HEAD_FUSED = True
+    a, b = res[True], res[False]
+    assert (a[2] - b[2]).abs().max().item() < 2e-6
+    assert (a[0] - b[0]).abs().max().item() < 2e-6
+    for ga, gb in zip(a[1], b[1]):
+        # the L1 loss's sign(out - x) can flip where out == x to the last bit: allow a few elements' worth of 1 / numel
+        assert (ga - gb).abs().max().item() <= 2e-3 * max(1e-6, gb.abs().max().item())

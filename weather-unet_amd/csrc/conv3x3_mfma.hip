@@ -496,3 +496,31 @@ extern "C" int wu_conv3x3_relu_pool_bits_fwd(const void* x, int ldx, const void*
     WU_LAUNCH_CHECK("conv3x3_mfma_v2 (+pool +bits)");
     return 0;
 }
+
+// conv3x3 + bias + ReLU of the last decoder conv AND the network's head, tanh(conv1x1(y) + b) (cunet.py:78-82), in one launch (round 4): the
+// head is 8 extra MFMAs per wave and tile on the packed registers of the conv's epilogue, so the stand-alone head kernel's re-read of y
+// (268 MB at B = 32 256x256) disappears; with y == NULL (a forward nobody differentiates) the 64-channel tensor is never written either.
+// LDS-DMA path only (bf16, Cout == 64, Cin in [64, 256)): ask wu_conv3x3_relu_head_supported first -- there is no fallback in here.
+extern "C" int wu_conv3x3_relu_head_supported(int H, int W, int ldx, int ldy, int Cin, int Cout, int dtype) {
+    return (g_wu_opt[WU_OPT_CONV_V2] && Cout == 64 && Cin < 256 && conv_v2_eligible(H, W, ldx, ldy, Cin, Cout, 1, dtype, false)) ? 1 : 0;
+}
+
+extern "C" int wu_conv3x3_relu_head_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                                        const float* head_w, const float* head_bias, float* out_nchw,
+                                        int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    WU_REQUIRE(N > 0 && H > 0 && W > 0 && x && w_packed && bias && head_w && head_bias && out_nchw, "conv3x3_relu_head_fwd: bad args");
+    WU_REQUIRE(wu_conv3x3_relu_head_supported(H, W, ldx, y ? ldy : 64, Cin, Cout, dtype), "conv3x3_relu_head_fwd: shape/dtype outside the fused head (ask wu_conv3x3_relu_head_supported)");
+    WU_REQUIRE(ldx >= Cin && (ldx * 2) % 16 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0, "conv3x3_relu_head_fwd: input alignment / ld");
+    if (y) WU_REQUIRE(ldy >= Cout && (ldy * 2) % 16 == 0 && ((uintptr_t)y % 16) == 0, "conv3x3_relu_head_fwd: output alignment / ld");
+    WU_REQUIRE(((uintptr_t)head_w % 16) == 0 && ((uintptr_t)out_nchw % 4) == 0, "conv3x3_relu_head_fwd: head weights must be 16-B aligned");
+    WU_REQUIRE((unsigned long long)N * 3 * H * W < (1ull << 32), "conv3x3_relu_head_fwd: image index must fit 32 bits");
+    hipStream_t s = (hipStream_t)stream;
+    wu_prof_pre(WU_FAM_CONV_FWD, s);
+    const int rc = conv_v2_launch(x, ldx, w_packed, bias, y, y ? ldy : 64, nullptr, 0, 0, N, H, W, Cin, Cout, WU_ACT_RELU, s, nullptr, 0, nullptr, nullptr, nullptr,
+                                  head_w, head_bias, out_nchw);
+    WU_REQUIRE(rc == 0, "conv3x3_relu_head_fwd: launch refused (%d)", rc);
+    wu_prof_post(WU_FAM_CONV_FWD, s, 2.0 * N * H * W * (double)Cout * (9.0 * Cin + 3.0),
+                 ((double)N * H * W * (Cin + (y ? Cout : 0)) + 9.0 * Cin * Cout) * 2 + (double)N * H * W * 12.0);
+    WU_LAUNCH_CHECK("conv3x3_mfma_v2 (+head)");
+    return 0;
+}

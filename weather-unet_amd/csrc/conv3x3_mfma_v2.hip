@@ -52,6 +52,9 @@ struct V2Args {
     int N, H, W, Cin, Cout, act;
     int tiles_x, tiles_y, cout_tiles, ntiles, prio_mode, strided;
     int w_resident;              // Cin == 64 and ONE cout tile: both weight chunks stay in LDS for the life of the workgroup
+    // GATED == 5 (round 4, cunet.py:78-82): the network's 1x1 head + tanh from the epilogue of the last decoder conv.  head_w = conv_last.weight
+    // [3][64] fp32, head_b [3], head_out the NCHW fp32 image; y may then be NULL (a forward nobody differentiates: the 64-channel tensor is never written)
+    const float* head_w; const float* head_b; float* head_out;
     unsigned long long* dbg;     // diagnostic: per-workgroup phase cycle sums (NULL in production)
 };
 
@@ -93,6 +96,11 @@ __device__ __forceinline__ uint32_t gate_mask2(int bits, int b) {
     const uint32_t lo = (uint32_t)((bits << (31 - b)) >> 31), hi = (uint32_t)((bits << (30 - b)) >> 31);
     return (lo & 0xffffu) | (hi << 16);
 }
+// tanh(s) = 1 - 2 / (exp(2 s) + 1) on the hardware exp2 / rcp units (the formula of thin.hip's stand-alone head kernel)
+__device__ __forceinline__ float fast_tanh(float s) {
+    const float e = __builtin_amdgcn_exp2f(s * 2.885390081777927f);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
@@ -108,7 +116,11 @@ template <int RPW_> struct AccT<true, RPW_> { using type = f32x4_t[RPW_][2][4]; 
 // GATED: 0 = forward; 1 / 2 = the data-gradient form (a gate in the epilogue, no bias) with the gate as a tensor / as bits;
 // 3 = forward (ReLU) that also writes the gate bits of its output; 4 = forward (ReLU) + 2x2 max-pool that also writes, per element of
 // its output, the gate bit AND the pool's arg-max bit (round 4: the max-pool backward then reads 2 bits instead of the tensor) -- separate instances so that
-// the gate-tensor prefetch registers (32 / 64), the bias registers (32) and neither of them are allocated as each case needs
+// the gate-tensor prefetch registers (32 / 64), the bias registers (32) and neither of them are allocated as each case needs;
+// 5 = forward (ReLU, Cout == 64, 8 waves) + the 64 -> 3 pointwise head + tanh (cunet.py:80-82) on the matrix cores: the packed bf16 registers of the
+// epilogue ARE the B operand of a 32x32x16 MFMA whose K block is their 16 channels (lane (pixel, half) holds channels 8 half .. 8 half + 7), the head's
+// weights are four A fragments built once per persistent workgroup -- rows 0..2 the bf16 high parts, rows 8..10 and 16..18 the first and second bf16 residuals of the fp32 weights, so
+// the products carry the weights exactly -- 8 extra MFMAs per wave and tile (144 in the K loop), three fp32 values per pixel leave as deferred dword stores
 template <int NW, int GATED>
 __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a) {
     using Q = KW<NW>;
@@ -239,6 +251,33 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         a16_lane[kw] = ((Q::RPW * wave) * K::HALO_W + l15 + kw) * 64 + ((q16 ^ (2 * (((l15 + kw) >> 2) & 1))) << 4);
     b16_lane = K::H_BYTES + l15 * 64 + ((q16 ^ (2 * ((l15 >> 2) & 1))) << 4);
 
+    // head A fragments (GATED == 5): K block kb = channels 16 kb .. + 15, lane (m = l31, half lh) holds row m's channels 16 kb + 8 lh + i
+    uint4 hA[4];
+    float hbias[3] = {0.f, 0.f, 0.f};
+    if constexpr (GATED == 5) {
+        // rows 0..2: bf16(w); rows 8..10: bf16(w - hi); rows 16..18: bf16(w - hi - lo) -- three terms carry an fp32 weight exactly (24 mantissa bits)
+        const int part = l31 >> 3, hrow = ((l31 & 7) < 3 && part < 3) ? (l31 & 7) : -1;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            uint32_t d[4] = {0u, 0u, 0u, 0u};
+            if (hrow >= 0) {
+                const float4 w0 = *(const float4*)(a.head_w + hrow * 64 + 16 * kb + 8 * lh);
+                const float4 w1 = *(const float4*)(a.head_w + hrow * 64 + 16 * kb + 8 * lh + 4);
+                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t hi = pack_bf16x2(wv[2 * i], wv[2 * i + 1]);
+                    const float r0 = wv[2 * i] - __builtin_bit_cast(float, hi << 16), r1 = wv[2 * i + 1] - __builtin_bit_cast(float, hi & 0xffff0000u);
+                    const uint32_t lo = pack_bf16x2(r0, r1);
+                    const float q0 = r0 - __builtin_bit_cast(float, lo << 16), q1 = r1 - __builtin_bit_cast(float, lo & 0xffff0000u);
+                    d[i] = part == 0 ? hi : (part == 1 ? lo : pack_bf16x2(q0, q1));
+                }
+            }
+            hA[kb] = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) hbias[c] = a.head_b[c];
+    }
     unsigned long long t_wait = 0, t_comp = 0, t_comp_rest = 0, t_epi_b1 = 0, t_epi_b2 = 0, t_epi_s = 0, t_mark = 0;
 #define WU_STAMP(acc_var) do { if (a.dbg) { const unsigned long long t_ = __builtin_readcyclecounter(); acc_var += t_ - t_mark; t_mark = t_; } } while (0)
     unsigned long long t_k0 = 0, t_r0 = 0;
@@ -262,6 +301,16 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
     unsigned ovb[Q::RPW];                         // the pending tile's gate words (forward with gate bits), stored after `ov`
     unsigned ovb_off = 0;                         // this lane's dword index of row 0's gate word
     bool ovb_pending = false;
+    // GATED == 5: the tile's head outputs (tanh applied), [row][channel], lanes of half 0 = pixel l31; stored after `ov` like the gate words
+    float ovh[Q::RPW][3];
+    unsigned ovh_off = 0;                         // this lane's float index of (row 0, channel 0) in head_out
+    bool ovh_pending = false;
+    const bool has_y = a.y != nullptr;            // (uniform) GATED == 5 may run without the 64-channel output
+    const unsigned plane = (unsigned)(a.H * a.W);
+    auto store_ovh = [&](int k) __attribute__((always_inline)) {       // k = 3 * row + channel
+        const int mi = k / 3, c = k % 3;
+        if (lh == 0 && ((ov_ok >> (8 * (mi >> 1) + (mi & 1))) & 1u)) a.head_out[ovh_off + (unsigned)c * plane + (unsigned)mi * (unsigned)a.W] = ovh[mi][c];
+    };
     auto store_ovb = [&](int mi) __attribute__((always_inline)) {
         if ((ov_ok >> (8 * (mi >> 1) + (mi & 1))) & 1u) a.gbits[ovb_off + (unsigned)mi * (unsigned)(a.W * 2 * a.cout_tiles)] = ovb[mi];
     };
@@ -323,14 +372,16 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
             // this wave's pieces of the current chunk must have landed.  Right after an interior tile's epilogue the 8
             // output stores are the YOUNGEST vector-memory ops and every DMA piece is older: vmcnt(8) retires the DMA
             // without draining the stores to HBM (vmcnt counts loads, stores and LDS-DMA together, in issue order).
-            if (stores_in_flight && bits_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q::NST + Q::RPW) : "memory");
+            if (GATED == 5 && stores_in_flight && has_y) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q::NST + 3 * Q::RPW) : "memory");
+            else if (GATED == 5 && stores_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * Q::RPW) : "memory");
+            else if (stores_in_flight && bits_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q::NST + Q::RPW) : "memory");
             else if (stores_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q::NST) : "memory");
             else dma_wait_all();
             stores_in_flight = false;
             WU_STAMP(t_wait);
             __syncthreads();     // ... and so have everyone else's; everyone is also done with the other buffer
             WU_STAMP(t_epi_b2);  // (diagnostic) chunk-top barrier time is folded into the 'barrier2' slot
-            if (last && (GATED == 0 || GATED == 3 || GATED == 4)) {      // requested in the LAST chunk: lands under its MFMAs, and its registers are free for `ov` before
+            if (last && (GATED == 0 || GATED == 3 || GATED == 4 || GATED == 5)) {      // requested in the LAST chunk: lands under its MFMAs, and its registers are free for `ov` before
                 const int ct_ = cur.ct;
                 if constexpr (M16) {
 #pragma unroll
@@ -420,8 +471,13 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                     // the previous tile's outputs, one store per step once this chunk's DMA pieces are out (they stay the
                     // youngest vector-memory ops: the next chunk-top wait is vmcnt(NST))
                     static_assert(2 * 5 >= Q::NP || NW != 8, "deferred stores must follow the last DMA piece");
-                    if (FIRST && ov_pending && step >= 5 && step < 5 + Q::NST) store_ov(step - 5);
+                    if (FIRST && ov_pending && (GATED != 5 || has_y) && step >= 5 && step < 5 + Q::NST) store_ov(step - 5);
                     if (GATED == 3 && FIRST && ovb_pending && step >= 5 + Q::NST && step < 5 + Q::NST + Q::RPW) store_ovb(step - 5 - Q::NST);
+                    // head outputs: two dword stores per step behind the tile's 16-byte stores (3 RPW = 6 of them at 8 waves: steps 13..15)
+                    if (GATED == 5 && FIRST && ovh_pending && step >= 5 + Q::NST && 2 * (step - 5 - Q::NST) < 3 * Q::RPW) {
+                        store_ovh(2 * (step - 5 - Q::NST));
+                        if (2 * (step - 5 - Q::NST) + 1 < 3 * Q::RPW) store_ovh(2 * (step - 5 - Q::NST) + 1);
+                    }
                     // pin the order: left alone, the scheduler sinks the fragment reads of the DMA-free steps (6..17) to just
                     // before their first use and waits lgkmcnt(0) in front of every MFMA
                     __builtin_amdgcn_sched_barrier(0);
@@ -492,7 +548,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                 }
             }
             buf = nxt;
-            if (FIRST && ov_pending) { stores_in_flight = ov_interior; bits_in_flight = ovb_pending; ov_pending = false; ovb_pending = false; }
+            if (FIRST && ov_pending) { stores_in_flight = ov_interior; bits_in_flight = ovb_pending; ov_pending = false; ovb_pending = false; ovh_pending = false; }
             if (FIRST) WU_STAMP(t_comp); else WU_STAMP(t_comp_rest);
         };
         do_chunk(0, std::true_type{}, std::false_type{});
@@ -548,6 +604,13 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
             unsigned gb[Q::RPW], sb[Q::RPW];
 #pragma unroll
             for (int i = 0; i < Q::RPW; ++i) gb[i] = sb[i] = 0u;
+            f32x16_t hacc[Q::RPW];                                   // GATED == 5: head products, rows = head channel (+ 8: residual part), columns = pixels
+            if constexpr (GATED == 5) {
+#pragma unroll
+                for (int mi = 0; mi < Q::RPW; ++mi)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) hacc[mi][i] = 0.f;
+            }
 #pragma unroll
             for (int mp = 0; mp < Q::RPW / 2; ++mp) {                // the wave's rows in vertical pairs (even, odd)
                 const int ohe = oh0 + Q::RPW * wave + 2 * mp, ow = ow0 + l31;
@@ -602,6 +665,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                             }
                             ov[((mp * 2 + ni) * 2 + (g >> 1)) * 2 + r] = v;       // stored from inside the next tile's first chunk
                             vr[r] = v;
+                            if constexpr (GATED == 5) mma(hacc[mi], hA[2 * ni + (g >> 1)], v);      // z[head channel][pixel] += Wh[:, 16 channels] * y[16 channels][pixel]
                             if ((GATED == 3 || GATED == 4) && ACT == WU_ACT_RELU)
                                 gb[2 * mp + r] |= nonzero_byte(v) << (8 * (2 * ni + (g >> 1)));
                         }
@@ -646,6 +710,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
                     }
                 }
             }
+            if constexpr (GATED == 5) {                   // bias + tanh; parked like `ov` (lanes of half 0 hold rows 0..3, 8..11 and 16..19 of the product)
+#pragma unroll
+                for (int mi = 0; mi < Q::RPW; ++mi)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) ovh[mi][c] = fast_tanh((hacc[mi][c] + (hacc[mi][4 + c] + hacc[mi][8 + c])) + hbias[c]);
+                ovh_off = (unsigned)(((size_t)n * 3 * a.H + oh0 + Q::RPW * wave) * a.W + ow0 + l31);
+                ovh_pending = true;
+            }
             if (GATED == 3 && ACT == WU_ACT_RELU) {       // parked like `ov`: issued from the next tile's first chunk
 #pragma unroll
                 for (int mi = 0; mi < Q::RPW; ++mi) ovb[mi] = gb[mi];
@@ -657,7 +729,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         using A1 = std::integral_constant<int, WU_ACT_RELU>;
         using A2 = std::integral_constant<int, WU_ACT_LEAKY>;
         using NoPool = std::false_type;
-        if constexpr (GATED == 4) {        // forward + ReLU + pool + gate / arg-max bits
+        if constexpr (GATED == 5) {        // forward + ReLU + pointwise head + tanh
+            epi_store(A1{}, A0{}, NoPool{});
+        } else if constexpr (GATED == 4) {        // forward + ReLU + pool + gate / arg-max bits
             epi_store(A1{}, A0{}, std::true_type{});
         } else if constexpr (GATED == 3) { // forward + gate bits: ReLU, no pool (conv_v2_launch)
             epi_store(A1{}, A0{}, NoPool{});
@@ -679,7 +753,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         // tile's first chunk relies on it).
         {
             const int ohw = oh0 + Q::RPW * wave, ow = ow0 + l31;
-            ov_img = a.y + img_pix * a.ldy;
+            ov_img = has_y ? a.y + img_pix * a.ldy : a.y;
             ov_off = (unsigned)(((ohw * a.W + ow) * a.ldy + co0 + 8 * lh) * 2);
             unsigned rows = 0;
 #pragma unroll
@@ -694,8 +768,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
         cur = advance(cur);
     }
     if (ov_pending) {                // the last tile's outputs
+        if (GATED != 5 || has_y) {
 #pragma unroll
-        for (int k = 0; k < Q::NST; ++k) store_ov(k);
+            for (int k = 0; k < Q::NST; ++k) store_ov(k);
+        }
+        if (GATED == 5 && ovh_pending) {
+#pragma unroll
+            for (int k = 0; k < 3 * Q::RPW; ++k) store_ovh(k);
+        }
         if (GATED == 3 && ovb_pending) {
 #pragma unroll
             for (int mi = 0; mi < Q::RPW; ++mi) store_ovb(mi);
@@ -721,8 +801,10 @@ bool conv_v2_eligible(int H, int W, int ldx, int ldy, int Cin, int Cout, int str
 
 int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
                    const void* egate, int ldegate, int egate_act, int N, int H, int W, int Cin, int Cout, int act, hipStream_t s,
-                   void* pool, int ldpool, void* gate_bits_out, const void* egate_bits, void* sel_bits_out) {
+                   void* pool, int ldpool, void* gate_bits_out, const void* egate_bits, void* sel_bits_out,
+                   const float* head_w, const float* head_b, float* head_out) {
     V2Args a;
+    a.head_w = head_w; a.head_b = head_b; a.head_out = head_out;
     a.pool = (bf16_t*)pool; a.ldpool = ldpool;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.egate = (const bf16_t*)egate;
     a.ldx = ldx; a.ldy = ldy; a.ldegate = ldegate; a.egate_act = egate_act; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act;
@@ -740,7 +822,7 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
     static thread_local bool attr_set = false;
     if (!attr_set) {
 #define WU_V2_ATTR(NW_, G_) (void)hipFuncSetAttribute((const void*)conv3x3_mfma_v2_kernel<NW_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-        WU_V2_ATTR(8, 0); WU_V2_ATTR(4, 0); WU_V2_ATTR(8, 1); WU_V2_ATTR(4, 1); WU_V2_ATTR(8, 2); WU_V2_ATTR(4, 2); WU_V2_ATTR(8, 3); WU_V2_ATTR(4, 3); WU_V2_ATTR(8, 4); WU_V2_ATTR(4, 4);
+        WU_V2_ATTR(8, 5); WU_V2_ATTR(8, 0); WU_V2_ATTR(4, 0); WU_V2_ATTR(8, 1); WU_V2_ATTR(4, 1); WU_V2_ATTR(8, 2); WU_V2_ATTR(4, 2); WU_V2_ATTR(8, 3); WU_V2_ATTR(4, 3); WU_V2_ATTR(8, 4); WU_V2_ATTR(4, 4);
 #undef WU_V2_ATTR
         attr_set = true;
     }
@@ -757,11 +839,15 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
         a.gbits = (unsigned*)gate_bits_out; a.sbits = (unsigned*)sel_bits_out;
         gated = 4;
     }
-    const bool nw4 = mode == 2 || (mode == 1 && Cin >= 256);
+    if (head_out) {                    // forward + ReLU + head: the 8-wave shape with one cout tile (checked by the caller)
+        if (gated != 0 || act != WU_ACT_RELU || pool || Cout != 64 || Cin >= 256) return -2;
+        gated = 5;
+    }
+    const bool nw4 = gated != 5 && (mode == 2 || (mode == 1 && Cin >= 256));
     a.w_resident = (!nw4 && Cin == 64 && a.cout_tiles == 1 && g_wu_opt[WU_OPT_CONV_W_RESIDENT]) ? 1 : 0;
 #define WU_V2_GO(NW_, G_) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<NW_, G_>), dim3((int)grid), dim3(NW_ * 64), 2 * K::BUF, s, a)
     if (nw4) { if (gated == 4) WU_V2_GO(4, 4); else if (gated == 3) WU_V2_GO(4, 3); else if (gated == 2) WU_V2_GO(4, 2); else if (gated == 1) WU_V2_GO(4, 1); else WU_V2_GO(4, 0); }
-    else { if (gated == 4) WU_V2_GO(8, 4); else if (gated == 3) WU_V2_GO(8, 3); else if (gated == 2) WU_V2_GO(8, 2); else if (gated == 1) WU_V2_GO(8, 1); else WU_V2_GO(8, 0); }
+    else { if (gated == 5) WU_V2_GO(8, 5); else if (gated == 4) WU_V2_GO(8, 4); else if (gated == 3) WU_V2_GO(8, 3); else if (gated == 2) WU_V2_GO(8, 2); else if (gated == 1) WU_V2_GO(8, 1); else WU_V2_GO(8, 0); }
 #undef WU_V2_GO
     return 0;
 }

@@ -11,7 +11,9 @@ int conv_v2_launch(const void* x, int ldx, const void* w, const float* bias, voi
                    // ReLU gate as bits (wu_conv3x3_fwd_bits): written by a forward with act == RELU / read by a data-gradient pass
                    void* gate_bits_out = nullptr, const void* egate_bits = nullptr,
                    // with pool != NULL and gate_bits_out: also the pool's arg-max bits (same word layout): the forward + pool + bits instance
-                   void* sel_bits_out = nullptr);
+                   void* sel_bits_out = nullptr,
+                   // head_out != NULL (act ReLU, Cout == 64, Cin < 256): the 64 -> 3 pointwise head + tanh from the same epilogue (wu_conv3x3_relu_head_fwd); y may be NULL
+                   const float* head_w = nullptr, const float* head_b = nullptr, float* head_out = nullptr);
 
 // Data gradient of a stride-2 conv as FOUR sparse-tap stride-1 convs, one per parity class (p, q) of the input site (conv3x3_mfma.hip):
 // site (2i + p, 2j + q) receives forward taps kh in {1} (p = 0) or {0, 2} (p = 1) only, so the classes take 1 / 2 / 2 / 4 of the nine

@@ -166,6 +166,24 @@ def conv3x3_relu_pool_bits(x, w_packed, bias, y, pool, gate_bits, sel_bits):
     return y, pool
 
 
+def conv3x3_head_supported(x, cout=64):
+    """True when conv + ReLU + the 64 -> 3 head + tanh can run as ONE launch for input x (wu_conv3x3_relu_head_supported)."""
+    if not x.is_cuda:
+        return False
+    n, cin, h, w = x.shape
+    return bool(_lib.load().wu_conv3x3_relu_head_supported(h, w, nhwc_ld(x), cout, cin, cout, dtype_code(x)))
+
+
+def conv3x3_relu_head(x, w_packed, bias, y, head_w, head_bias, out_nchw):
+    """y = ReLU(conv3x3(x) + bias) and out_nchw = tanh(head_w . y + head_bias) in one launch (cunet.py:78-82); y may be None (the 64-channel
+    tensor is then never written).  Callers check conv3x3_head_supported(x) first."""
+    n, cin, h, w = x.shape
+    _lib.call("wu_conv3x3_relu_head_fwd", x.data_ptr(), nhwc_ld(x), w_packed.data_ptr(), bias.data_ptr(),
+              y.data_ptr() if y is not None else None, nhwc_ld(y) if y is not None else 64,
+              head_w.data_ptr(), head_bias.data_ptr(), out_nchw.data_ptr(), n, h, w, cin, 64, dtype_code(x), stream_ptr())
+    return y, out_nchw
+
+
 def maxpool2_bwd_bits(gate_bits, sel_bits, gy, dx, dskip=None):
     """MaxPool2d(2) backward + skip-gradient sum + ReLU gate from the two bit planes the forward conv left (wu_maxpool2_bwd_bits)."""
     n, c, h, w = dx.shape

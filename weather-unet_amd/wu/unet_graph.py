@@ -34,6 +34,9 @@ POOL_BITS = os.environ.get("WU_POOL_BITS", "1") == "1"
 # (down1.2), its reducer and this kernel ran one after the other for 230 us after the main stream's last data gradient had finished;
 # on the main stream it runs beside that tail instead of behind it.
 C3_WGRAD_ON_SIDE = os.environ.get("WU_C3_WGRAD_SIDE", "0") == "1"
+# the 1x1 head + tanh computed in the epilogue of the last decoder conv (csrc/conv3x3_mfma_v2.hip, GATED = 5; cunet.py:78-82) instead of by a
+# kernel of its own that re-reads the 64-channel tensor; an undifferentiated forward then never writes that tensor (round 4; A/B switch)
+HEAD_FUSED = os.environ.get("WU_HEAD_FUSED", "1") == "1"
 _SIDE = {}
 _ORDER_EVENTS = {}
 LIGHT_EVENTS = os.environ.get("WU_LIGHT_EVENTS", "1") == "1"
@@ -281,11 +284,17 @@ class UNetFn(Function):
         st1 = K.adain_stats(u2b, eps)
         mb1 = K.adain_upcat(u2b, st1, ys[2], ym[2], cat1, p_drop, seeds[2], want_bits, seed_dev, inj[2])
         u1a = mid_conv("dconv_up1", cat1, _new(n, 64, h, w, dt, dev))
-        u1b = K.conv3x3(u1a, pk["dconv_up1.2"][0], wb["dconv_up1"][3], _new(n, 64, h, w, dt, dev), 1, RELU)
-
-        # ---- head (cunet.py:80-82) ----
+        # ---- last decoder conv + head (cunet.py:78-82) ----
         w3c = w_last.detach().reshape(3, 64).contiguous()
-        out = K.conv1x1_tanh(u1b, w3c, b_last, torch.empty((n, 3, h, w), dtype=torch.float32, device=dev))
+        out = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
+        if HEAD_FUSED and w3c.data_ptr() % 16 == 0 and K.conv3x3_head_supported(u1a):
+            # one launch: the head is 8 extra MFMAs per tile on the conv epilogue's registers; a forward nobody differentiates does not even
+            # write the 64-channel tensor (it has no other consumer)
+            u1b = _new(n, 64, h, w, dt, dev) if want_bits else None
+            K.conv3x3_relu_head(u1a, pk["dconv_up1.2"][0], wb["dconv_up1"][3], u1b, w3c, b_last.detach(), out)
+        else:
+            u1b = K.conv3x3(u1a, pk["dconv_up1.2"][0], wb["dconv_up1"][3], _new(n, 64, h, w, dt, dev), 1, RELU)
+            K.conv1x1_tanh(u1b, w3c, b_last, out)
 
         if want_bits:
             ctx.save_for_backward(x, a1, cat1, p1, a2, cat2, p2, a3, cat3, p3, a4, b4, u3a, u3b, u2a, u2b, u1a, u1b, out,
