@@ -47,7 +47,9 @@ int wu_cu_count(void);
  * the re-entrant launcher contract.  A production caller never touches it: the defaults ARE the production
  * choices and every variant computes identical results; set it only from a single-threaded benchmark harness, between launches.
  *   0: conv LDS-DMA path (0 off = generic template, 1 auto wave shape (default), 2 always 4 waves, 3 always 8 waves)
- *   1: persistent tile loop on/off      2: LDS-DMA wgrad (0 off, 1 = 8 waves (default), 2 = 4 waves)      3: unused
+ *   1: persistent tile loop on/off      2: LDS-DMA wgrad (0 off, 1 = 8 waves (default), 2 = 4 waves)
+ *   3: stride-1 bf16 convs on images at most 16 pixels wide on the small-image kernel (128-pixel tiles, in-workgroup K split, stacked images; default 1 = where the generic template's 256-pixel tiles
+ *      would under-fill the chip or lie mostly outside the image, 2 = always, 0 = never)
  *   4: wgrad DMA issue spread over K-steps (default 1)   5: first conv (0 matrix cores in bf16 (default), 1 rows kernel, 2 VALU kernel)
  *   6: static priority for the younger wave half (default 1)   7: grid-strided tile assignment (default 1)
  *   8: AdaIN-upsample backward (0 = 16-tap gather, 1 = default: bf16 with keep bits streams through an LDS ring, everything else marches

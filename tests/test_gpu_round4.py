@@ -547,3 +547,46 @@ def test_unet_forward_with_and_without_the_fused_head():
     for ga, gb in zip(a[1], b[1]):
         # the L1 loss's sign(out - x) can flip where out == x to the last bit: allow a few elements' worth of 1 / numel
         assert (ga - gb).abs().max().item() <= 2e-3 * max(1e-6, gb.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# 3x3 convs on images at most 16 pixels wide (csrc/conv3x3_small.hip: the estimator's layer3 / layer4, classifier.py:106)
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [
+    (5, 256, 256, 16, 16, False),     # layer3's shape: one image = two 8-row tiles
+    (5, 128, 64, 8, 8, False),        # layer4's geometry: two 8x8 images stacked per tile, an odd batch (a half-empty last tile)
+    (3, 64, 128, 13, 9, True),        # ragged, gated (data-gradient form): tile rows and columns past the image
+    (7, 96, 64, 5, 3, False),         # 4-wide tiles, six 5-row images per 32-row tile and two unused rows
+    (9, 64, 64, 4, 4, True),          # eight 4x4 images per tile
+    (2, 128, 128, 24, 16, True),      # three row tiles per image
+    (1, 32, 64, 1, 1, False),         # a single pixel
+])
+def test_small_image_conv_vs_generic_and_fp32(case):
+    """Same products, another summation grouping (the K range split between wave pairs): within two bf16 ulps of the generic template's
+    output and as close to an fp32 conv of the same bf16 operands as that one is."""
+    import torch.nn.functional as F
+    from wu import _lib, kernels as K
+    from wu.layout import as_nhwc
+    n, ci, co, h, w, gated = case
+    dev = _dev()
+    x = as_nhwc(_rand((n, ci, h, w), 31, -0.3, 0.7).to(dev), _lib.BF16)
+    wt = (_rand((co, ci, 3, 3), 32) * (6.0 / (9 * ci)) ** 0.5).to(dev)
+    wf, _ = K.pack_conv3x3(wt, _lib.BF16)
+    b = _rand((co,), 33, -0.5, 0.5).to(dev)
+    eg = as_nhwc(_rand((n, co, h, w), 34).to(dev), _lib.BF16) if gated else None
+    res = {}
+    try:
+        for opt in (1, 0):
+            _lib.call("wu_set_option", 3, 2 if opt else 0)
+            y = torch.full((n, h, w, co), float("nan"), dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2)
+            K.conv3x3(x, wf, None if gated else b, y, 1, K.ACT_NONE if gated else K.ACT_RELU, egate=eg, egate_act=K.ACT_RELU if gated else K.ACT_NONE)
+            torch.cuda.synchronize()
+            res[opt] = y.float().cpu()
+    finally:
+        _lib.call("wu_set_option", 3, 1)
+    assert not torch.isnan(res[1]).any()
+    ref = F.conv2d(x.float().cpu(), wt.to(torch.bfloat16).float().cpu(), None if gated else b.cpu(), padding=1)
+    ref = ref * (eg.float().cpu() > 0) if gated else torch.relu(ref)
+    scale = max(1.0, ref.abs().max().item())
+    assert (res[1] - res[0]).abs().max().item() <= 2 * scale * 2.0 ** -8
+    assert (res[1] - ref).abs().max().item() <= scale * 2.0 ** -8 + 1e-6

@@ -398,6 +398,15 @@ extern "C" int wu_conv3x3_fwd(const void* x, int ldx, const void* w_packed, cons
     // Round 4: stride 2 goes to the gathered-row form of the persistent LDS-DMA GEMM (option 15; resnet.hip) where its shape allows
     // (stride 1 on small images was measured too: 256 -> 256 @16x16 26.6 us against 24.1 on the register-staged kernel -- nine L2 reads of every row
     //  against a halo in LDS -- and 512 -> 512 @8x8 48 against 68 only from batch 64: not taken)
+    // Round 4 (later): small images on their own kernel -- on a 16x16 image the 256-pixel tile of the template below is the whole image (128 workgroups
+    // at B = 32), on 8x8 three quarters of it lie outside
+    if (dtype == WU_BF16 && !m && stride == 1 && g_wu_opt[WU_OPT_CONV_SMALL] &&
+        conv_small_launch(x, ldx, w_packed, bias, y, ldy, egate, ldegate, egate_act, N, H, W, Cin, Cout, act, s) == 0) {
+        const double pix = (double)N * H * W;
+        wu_prof_post(fam, s, 2.0 * pix * Cout * 9.0 * Cin, (pix * (Cin + Cout) + 9.0 * Cin * Cout) * esz);
+        WU_LAUNCH_CHECK("conv3x3 (small images)");
+        return 0;
+    }
     if (dtype == WU_BF16 && !m && stride == 2 && (g_wu_opt[WU_OPT_PW3] & 7) &&
         conv3x3_gather_launch(x, ldx, w_packed, bias, y, ldy, egate, ldegate, egate_act, N, H, W, Cin, Cout, stride, act, s) == 0) {
         const double pix = (double)N * a.Ho * a.Wo;

@@ -36,7 +36,7 @@ extern void* g_wu_dbg_ptr;
 #define WU_OPT_CONV_V2 0
 #define WU_OPT_CONV_PERSISTENT 1
 #define WU_OPT_WGRAD_V2 2
-#define WU_OPT_CONV_CT_SLOWEST 3
+#define WU_OPT_CONV_SMALL 3
 #define WU_OPT_WGRAD_DMA_INTERLEAVE 4
 #define WU_OPT_C3_ROWS 5
 #define WU_OPT_CONV_PRIO 6

@@ -60,7 +60,7 @@ extern "C" int wu_stream_order_after(void* waiter, void* producer, void* event) 
 }
 
 // tuning switches (A/B benchmarking of kernel variants inside one process; defaults are the production choices)
-int g_wu_opt[16] = {/*CONV_V2*/ 1, /*CONV_PERSISTENT*/ 1, /*WGRAD_V2*/ 1, /*CONV_CT_SLOWEST*/ 0, /*WGRAD_DMA_INTERLEAVE*/ 1, /*C3_ROWS*/ 0, /*CONV_PRIO*/ 1, /*CONV_STRIDED*/ 1, /*ADAIN_BWD_MARCH*/ 1, /*ADAIN_FWD_MARCH*/ 1, /*GRID_CUS*/ 0, /*CONV_W_RESIDENT*/ 1, /*PW_TILE*/ 0, /*IMG3_TILED*/ 1, /*S2_DGRAD_PARITY*/ 1, /*PW3: D = 2, eight waves, from 128 tiles*/ 2 + 8 + (128 << 5)};
+int g_wu_opt[16] = {/*CONV_V2*/ 1, /*CONV_PERSISTENT*/ 1, /*WGRAD_V2*/ 1, /*CONV_SMALL*/ 1, /*WGRAD_DMA_INTERLEAVE*/ 1, /*C3_ROWS*/ 0, /*CONV_PRIO*/ 1, /*CONV_STRIDED*/ 1, /*ADAIN_BWD_MARCH*/ 1, /*ADAIN_FWD_MARCH*/ 1, /*GRID_CUS*/ 0, /*CONV_W_RESIDENT*/ 1, /*PW_TILE*/ 0, /*IMG3_TILED*/ 1, /*S2_DGRAD_PARITY*/ 1, /*PW3: D = 2, eight waves, from 128 tiles*/ 2 + 8 + (128 << 5)};
 void* g_wu_dbg_ptr = nullptr;   // diagnostic stamp buffer (256 workgroups x 8 waves x 8 u64), NULL in production
 extern "C" int wu_set_debug_buffer(void* p) { g_wu_dbg_ptr = p; return 0; }
 extern "C" int wu_set_option(int key, int value) {

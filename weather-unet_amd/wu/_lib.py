@@ -131,6 +131,16 @@ def load():
             fn.restype = res
             fn.argtypes = args
         _lib = lib
+        # WU_SET_OPTIONS="key=value,...": diagnostic switches of the library (include/wu_kernels.h, wu_set_option) from the environment --
+        # same-box A/B runs of a whole benchmark (scratch/ab_gan_env.sh); announced, never silent
+        opts = os.environ.get("WU_SET_OPTIONS")
+        if opts:
+            import sys
+            print(f"[wu] WU_SET_OPTIONS={opts}", file=sys.stderr, flush=True)
+            for kv in opts.split(","):
+                k, _, v = kv.partition("=")
+                if lib.wu_set_option(int(k), int(v)) != 0:
+                    raise RuntimeError(f"WU_SET_OPTIONS: wu_set_option({k}, {v}) refused")
     return _lib
 
 
