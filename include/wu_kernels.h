@@ -160,6 +160,15 @@ int wu_conv3x3_relu_pool_fwd(const void* x, int ldx, const void* w_packed, const
 int wu_conv3x3_relu_pool_bits_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                                   void* pool, int ldpool, void* gate_bits_out, void* sel_bits_out,
                                   int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+/* 3x3 conv, stride 1, bf16, on images at most 16 pixels wide with CHUNK-MAJOR weights (round 4; the frozen estimator's layer3 / layer4 convs and their
+ * data gradient, classifier.py:106): w_chunked[Cin / 32][9][Cout][32] = the pack of wu_pack_conv3x3 ([9][Cout][Cin]) viewed as [9][Cout][Cin / 32][32] and
+ * permuted (2, 0, 1, 3), so that a chunk's tap slab is 4 KiB contiguous (the small-image kernel is bound by the bytes it pulls out of L2).  y = act(conv(x) +
+ * bias) [* act'(egate)] exactly as wu_conv3x3_fwd computes it on the small-image kernel (option 3).  wu_conv3x3_small_supported: 1 = the shape runs there
+ * and the dispatch rule prefers it to the generic template; otherwise call wu_conv3x3_fwd with the ordinary pack. */
+int wu_conv3x3_small_supported(int N, int H, int W, int ldx, int ldy, int ldegate, int Cin, int Cout);
+int wu_conv3x3_small_fwd(const void* x, int ldx, const void* w_chunked, const float* bias, void* y, int ldy,
+                         const void* egate, int ldegate, int egate_act, int N, int H, int W, int Cin, int Cout, int act, void* stream);
+
 /* The last decoder conv AND the network's head in one launch (round 4; cunet.py:78-82: dconv_up1[2] + ReLU, then tanh(conv_last(y))):
  * y = ReLU(conv3x3(x) + bias) as above and out_nchw[N][3][H][W] (fp32) = tanh(head_w[3][64] . y + head_bias), the head computed on the matrix
  * cores from the conv epilogue's packed registers (head weights split into three bf16 terms: fp32-exact products of the STORED

@@ -55,9 +55,13 @@ for name, B, ci, co, h, w, gated in cases:
         t = graph_time(fn)
         res[opt] = (t, y.float().clone())
     _lib.call("wu_set_option", 3, 1)
+    wc = K.chunk_major(wf)
+    yc = torch.full((B, h, w, co), float("nan"), dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2)
+    tc = graph_time(lambda: K.conv3x3_small(x, wc, None if gated else b, yc, act, egate=eg, egate_act=K.ACT_RELU if gated else K.ACT_NONE))
+    same = torch.equal(yc.float(), res[1][1])
     fl = 2.0 * B * h * w * 9 * ci * co
     d = (res[1][1] - res[0][1]).abs().max().item()
-    line = f"{name:30s} small {res[1][0]:7.1f} us {fl / res[1][0] / 1e6:6.0f} TF/s | generic {res[0][0]:7.1f} us {fl / res[0][0] / 1e6:6.0f} TF/s | max|small-generic| {d:.3e}"
+    line = f"{name:30s} chunk-major {tc:7.1f} us {fl / tc / 1e6:6.0f} TF/s ({'bit-identical' if same else 'DIFFERS'}) | small {res[1][0]:7.1f} us {fl / res[1][0] / 1e6:6.0f} TF/s | generic {res[0][0]:7.1f} us {fl / res[0][0] / 1e6:6.0f} TF/s | max|small-generic| {d:.3e}"
     if check_cpu and fl < 3e10:
         ref = F.conv2d(x.float().cpu(), wt.to(torch.bfloat16).float().cpu(), None if gated else b.cpu(), padding=1)
         ref = ref * (eg.float().cpu() > 0) if gated else torch.relu(ref)

@@ -560,6 +560,7 @@ def test_unet_forward_with_and_without_the_fused_head():
     (9, 64, 64, 4, 4, True),          # eight 4x4 images per tile
     (2, 128, 128, 24, 16, True),      # three row tiles per image
     (1, 32, 64, 1, 1, False),         # a single pixel
+    (40, 64, 64, 2, 2, True),         # 2x2 images: thirteen per tile (the stacked halo image is capped at 320 pixels)
 ])
 def test_small_image_conv_vs_generic_and_fp32(case):
     """Same products, another summation grouping (the K range split between wave pairs): within two bf16 ulps of the generic template's
@@ -585,6 +586,11 @@ def test_small_image_conv_vs_generic_and_fp32(case):
     finally:
         _lib.call("wu_set_option", 3, 1)
     assert not torch.isnan(res[1]).any()
+    # chunk-major weights (wu_conv3x3_small_fwd, the estimator's form): the same kernel reading the same numbers from another address
+    yc = torch.full((n, h, w, co), float("nan"), dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2)
+    K.conv3x3_small(x, K.chunk_major(wf), None if gated else b, yc, K.ACT_NONE if gated else K.ACT_RELU, egate=eg, egate_act=K.ACT_RELU if gated else K.ACT_NONE)
+    torch.cuda.synchronize()
+    assert torch.equal(yc.float().cpu(), res[1])
     ref = F.conv2d(x.float().cpu(), wt.to(torch.bfloat16).float().cpu(), None if gated else b.cpu(), padding=1)
     ref = ref * (eg.float().cpu() > 0) if gated else torch.relu(ref)
     scale = max(1.0, ref.abs().max().item())

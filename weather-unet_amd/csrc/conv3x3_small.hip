@@ -32,6 +32,10 @@ struct SmArgs {
     int tw_log2, ipt;            // tile width 1 << tw_log2; images stacked per tile (1: the tile lies inside one image)
     int tiles_x, tiles_y, cout_tiles;
     int halo_w, halo_h, halo_pix;
+    // weights: 0 = the library's pack [tap][Cout][Cin] (a chunk's slab = 64-byte pieces of 2 Cin-byte rows: every 128-byte line is fetched for half its
+    // bytes, and its other half one chunk later from L2 again); 1 = chunk-major [Cin / 32][tap][Cout][32] (wu_conv3x3_small_fwd: a tap's 64 rows of a
+    // chunk are 4 KiB contiguous).  The kernel is bound by the bytes it pulls out of L2 (all 256 workgroups stream one of four weight slabs): -25 %
+    int w_chunked;
 };
 
 __device__ __forceinline__ int swz_off(int row, int slot) { return row * kCB + ((slot ^ ((row >> 2) & 3)) << 4); }
@@ -83,8 +87,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(const SmArgs a) {
     }
     // weights: piece 4 j + wave = rows 16 wave + (lane >> 2) of tap j's [64][32-channel] slab: one per-lane offset, the tap travels in the scalar offset
     const int wco = 16 * wave + (lane >> 2);
-    const unsigned woff = (unsigned)((((size_t)(co0 + wco)) * a.Cin + (((lane & 3) ^ ((wco >> 2) & 3)) * 8)) * 2);
-    const unsigned wtap_bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)((size_t)a.Cout * a.Cin * 2));
+    const unsigned wsl = (unsigned)(((lane & 3) ^ ((wco >> 2) & 3)) * 8);
+    const unsigned woff = a.w_chunked ? (unsigned)(((co0 + wco) * 32 + wsl) * 2) : (unsigned)((((size_t)(co0 + wco)) * a.Cin + wsl) * 2);
+    const unsigned wtap_bytes = (unsigned)__builtin_amdgcn_readfirstlane(a.w_chunked ? a.Cout * 64 : (int)((size_t)a.Cout * a.Cin * 2));
+    const unsigned wchunk_bytes = (unsigned)__builtin_amdgcn_readfirstlane(a.w_chunked ? 9 * a.Cout * 64 : 64);      // from one 32-channel chunk to the next
     const wu_rsrc_t rs_x = wu_make_rsrc(a.x, (unsigned)(((size_t)a.N * a.H * a.W * a.ldx) * 2));
     const wu_rsrc_t rs_w = wu_make_rsrc(a.w, (unsigned)((size_t)9 * a.Cout * a.Cin * 2));
     const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(const SmArgs a) {
 #pragma unroll
         for (int k = 0; k < NHK; ++k) wu_dma16b(hoff[k], rs_x, (unsigned)c0 * 2, __builtin_amdgcn_readfirstlane(lds + k * 4096));
 #pragma unroll
-        for (int j = 0; j < 9; ++j) wu_dma16b(woff, rs_w, (unsigned)c0 * 2 + (unsigned)j * wtap_bytes, __builtin_amdgcn_readfirstlane(lds + HALO_BYTES + j * 4096));
+        for (int j = 0; j < 9; ++j) wu_dma16b(woff, rs_w, (unsigned)(c0 >> 5) * wchunk_bytes + (unsigned)j * wtap_bytes, __builtin_amdgcn_readfirstlane(lds + HALO_BYTES + j * 4096));
     };
 
     // ---- per-lane fragment addresses (k-step kpart: 16-byte slots 2 kpart + lh) ----
@@ -217,18 +223,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(const SmArgs a) {
 
 // 0 = launched; 1 = not this kernel's shape (the caller falls back to the generic template)
 int conv_small_launch(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy, const void* egate, int ldegate, int egate_act,
-                      int N, int H, int W, int Cin, int Cout, int act, hipStream_t s) {
+                      int N, int H, int W, int Cin, int Cout, int act, hipStream_t s, int w_chunked, int mode) {
+    // mode: 0 = launch if the shape allows and the dispatch rule below prefers this kernel; 1 = only answer (0 = would launch); 2 = launch whatever the rule says
     if (W > 16 || Cin % 32 != 0 || Cout % kBN != 0) return 1;
     const int ldmax = ldx > ldy ? (ldx > ldegate ? ldx : ldegate) : (ldy > ldegate ? ldy : ldegate);
     if ((unsigned long long)N * H * W * (unsigned long long)ldmax >= (1ull << 31)) return 1;
     SmArgs a;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w_packed; a.bias = bias; a.y = (bf16_t*)y; a.egate = (const bf16_t*)egate;
     a.ldx = ldx; a.ldy = ldy; a.ldegate = ldegate; a.egate_act = egate_act; a.act = act;
-    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.w_chunked = w_chunked;
     a.tw_log2 = W > 8 ? 4 : (W > 4 ? 3 : 2);
     const int TW = 1 << a.tw_log2, TH = kTP >> a.tw_log2;
     a.ipt = H < TH ? TH / H : 1;
     if (a.ipt < 1) a.ipt = 1;
+    while (a.ipt > 1 && a.ipt * (H + 2) * (TW + 2) > 320) --a.ipt;       // the stacked halo image must fit 5 pieces per wave (tiny images: fewer per tile)
     a.tiles_x = cdiv(W, TW);
     a.tiles_y = a.ipt > 1 ? 1 : cdiv(H, TH);
     a.cout_tiles = Cout / kBN;
@@ -243,10 +251,11 @@ int conv_small_launch(const void* x, int ldx, const void* w_packed, const float*
     if (grid >= (1ll << 31)) return 1;
     // Where the generic template's 256-pixel tiles fill the chip AND lie inside the image (W > 8: a 16-wide tile is 16 rows), it stages the weight slab
     // once per 256 pixels instead of once per 128 and wins (256 -> 256 @16x16: B = 64 27.3 vs 31.6 us, B = 128 42.6 vs 60.1; B = 32 24.1 vs 16.2)
-    if (W > 8 && H >= 16 && g_wu_opt[WU_OPT_CONV_SMALL] != 2) {
+    if (W > 8 && H >= 16 && g_wu_opt[WU_OPT_CONV_SMALL] != 2 && mode != 2) {
         const long long generic_grid = (long long)N * cdiv(H, 16) * a.cout_tiles;
         if (generic_grid * 4 >= (long long)wu_num_cus() * 3) return 1;
     }
+    if (mode == 1) return 0;
     const int depth = nhk <= 4 ? 3 : 2;                  // three chunk buffers where they fit the CU's 160 KiB
     const size_t lds = (size_t)depth * (nhk * 4096 + 9 * kBN * kCB);     // >= the 32-KiB reduction image and the 18-KiB epilogue image
     static thread_local bool attr_set = false;
@@ -259,5 +268,30 @@ int conv_small_launch(const void* x, int ldx, const void* w_packed, const float*
     if (nhk <= 3) hipLaunchKernelGGL((conv3x3_small_kernel<3, 3>), dim3((int)grid), dim3(256), lds + (3 - nhk) * 3 * 4096, s, a);
     else if (nhk == 4) hipLaunchKernelGGL((conv3x3_small_kernel<4, 3>), dim3((int)grid), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((conv3x3_small_kernel<5, 2>), dim3((int)grid), dim3(256), lds, s, a);
+    return 0;
+}
+
+// The estimator's 3x3 convs on small images with CHUNK-MAJOR weights (round 4): w_chunked = [Cin / 32][9 taps][Cout][32] bf16, i.e. the library's pack
+// [9][Cout][Cin] viewed as [9][Cout][Cin / 32][32] and permuted (2, 0, 1, 3) -- for frozen weights (classifier.py:106, eval mode) a one-off
+// re-arrangement at plan time.  Same arithmetic as wu_conv3x3_fwd on the small-image kernel; callers ask wu_conv3x3_small_supported first (1 = this
+// shape runs on the small-image kernel AND the dispatch rule prefers it to the generic template).
+extern "C" int wu_conv3x3_small_supported(int N, int H, int W, int ldx, int ldy, int ldegate, int Cin, int Cout) {
+    if (!g_wu_opt[WU_OPT_CONV_SMALL]) return 0;
+    return conv_small_launch(nullptr, ldx, nullptr, nullptr, nullptr, ldy, nullptr, ldegate, 0, N, H, W, Cin, Cout, 0, nullptr, 1, 1) == 0 ? 1 : 0;
+}
+
+extern "C" int wu_conv3x3_small_fwd(const void* x, int ldx, const void* w_chunked, const float* bias, void* y, int ldy,
+                                    const void* egate, int ldegate, int egate_act, int N, int H, int W, int Cin, int Cout, int act, void* stream) {
+    WU_REQUIRE(N > 0 && H > 0 && W > 0 && x && y && w_chunked, "conv3x3_small_fwd: bad args");
+    WU_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0 && ldx >= Cin && ldy >= Cout && (ldx * 2) % 16 == 0 && (ldy * 2) % 16 == 0, "conv3x3_small_fwd: bad channels / ld");
+    WU_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)w_chunked % 16) == 0, "conv3x3_small_fwd: pointers must be 16-B aligned");
+    if (egate) WU_REQUIRE(((uintptr_t)egate % 16) == 0 && (ldegate * 2) % 16 == 0 && ldegate >= Cout, "conv3x3_small_fwd: bad egate");
+    hipStream_t s = (hipStream_t)stream;
+    wu_prof_pre(WU_FAM_CONV_FWD, s);
+    const int rc = conv_small_launch(x, ldx, w_chunked, bias, y, ldy, egate, egate ? ldegate : 0, egate_act, N, H, W, Cin, Cout, act, s, 1, 2);
+    WU_REQUIRE(rc == 0, "conv3x3_small_fwd: shape outside the small-image kernel (ask wu_conv3x3_small_supported)");
+    const double pix = (double)N * H * W;
+    wu_prof_post(WU_FAM_CONV_FWD, s, 2.0 * pix * Cout * 9.0 * Cin, (pix * (Cin + Cout) + 9.0 * Cin * Cout) * 2);
+    WU_LAUNCH_CHECK("conv3x3 (small images, chunk-major weights)");
     return 0;
 }

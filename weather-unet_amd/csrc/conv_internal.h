@@ -33,4 +33,7 @@ int conv_s2_dgrad_gather_launch(const void* dy, int lddy, const void* w_dgrad, v
 // 3 x 3 conv, stride 1, bf16, on images at most 16 pixels wide (conv3x3_small.hip: 128-pixel x 64-cout tiles, K split between wave pairs, images stacked
 // in a tile): the estimator's layer3 / layer4 convs and their data gradient.  0 = launched, 1 = not applicable (fall back to conv3x3_mfma_kernel).
 int conv_small_launch(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy, const void* egate, int ldegate, int egate_act,
-                      int N, int H, int W, int Cin, int Cout, int act, hipStream_t s);
+                      int N, int H, int W, int Cin, int Cout, int act, hipStream_t s,
+                      // w_chunked: weights in chunk-major order (wu_conv3x3_small_fwd); mode 0 = launch where the dispatch rule prefers this kernel,
+                      // 1 = only answer whether it would, 2 = launch whatever the rule says
+                      int w_chunked = 0, int mode = 0);

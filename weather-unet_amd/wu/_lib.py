@@ -49,6 +49,8 @@ SIGNATURES = {
     "wu_conv3x3_fwd_bits": (I, [P, I, P, P, P, I, P, P, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_relu_pool_fwd": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_relu_pool_bits_fwd": (I, [P, I, P, P, P, I, P, I, P, P, I, I, I, I, I, I, P]),
+    "wu_conv3x3_small_supported": (I, [I, I, I, I, I, I, I, I]),
+    "wu_conv3x3_small_fwd": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, I, I, P]),
     "wu_conv3x3_relu_head_supported": (I, [I, I, I, I, I, I, I]),
     "wu_conv3x3_relu_head_fwd": (I, [P, I, P, P, P, I, P, P, P, I, I, I, I, I, I, P]),
     "wu_maxpool2_bwd_bits": (I, [P, P, P, I, P, I, P, I, I, I, I, I, I, P]),

@@ -166,6 +166,29 @@ def conv3x3_relu_pool_bits(x, w_packed, bias, y, pool, gate_bits, sel_bits):
     return y, pool
 
 
+def conv3x3_small_supported(x, cout):
+    """True when a stride-1 3x3 conv of x into `cout` channels belongs on the small-image kernel (wu_conv3x3_small_supported)."""
+    if not x.is_cuda or dtype_code(x) != _lib.BF16:
+        return False
+    n, cin, h, w = x.shape
+    return bool(_lib.load().wu_conv3x3_small_supported(n, h, w, nhwc_ld(x), cout, cout, cin, cout))
+
+
+def chunk_major(w_packed):
+    """[9][Cout][Cin] (pack_conv3x3) -> [Cin / 32][9][Cout][32]: the weight order of wu_conv3x3_small_fwd."""
+    t, co, ci = w_packed.shape
+    return w_packed.view(t, co, ci // 32, 32).permute(2, 0, 1, 3).contiguous()
+
+
+def conv3x3_small(x, w_chunked, bias, y, act=ACT_NONE, egate=None, egate_act=ACT_NONE):
+    """y = act(conv3x3(x) + bias) [* act'(egate)] on the small-image kernel with chunk-major weights (wu_conv3x3_small_fwd)."""
+    n, cin, h, w = x.shape
+    ep, eld = _pl(egate)
+    _lib.call("wu_conv3x3_small_fwd", x.data_ptr(), nhwc_ld(x), w_chunked.data_ptr(), bias.data_ptr() if bias is not None else None,
+              y.data_ptr(), nhwc_ld(y), ep, eld, egate_act, n, h, w, cin, y.shape[1], act, stream_ptr())
+    return y
+
+
 def conv3x3_head_supported(x, cout=64):
     """True when conv + ReLU + the 64 -> 3 head + tanh can run as ONE launch for input x (wu_conv3x3_relu_head_supported)."""
     if not x.is_cuda:

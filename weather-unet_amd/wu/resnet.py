@@ -249,6 +249,15 @@ class ResNet101Estimator(nn.Module):
 # ----------------------------------------------------------------------------------------------
 # the network body as one autograd node
 # ----------------------------------------------------------------------------------------------
+def _chunked(c2, key):
+    """Chunk-major copy of a frozen 3x3 conv's packed weights (K.chunk_major), made the first time the small-image kernel asks for it and kept
+    with the plan entry (the plan is rebuilt when the estimator's state changes)."""
+    ck = key + "_chunked"
+    if ck not in c2:
+        c2[ck] = K.chunk_major(c2[key])
+    return c2[ck]
+
+
 def _half(v, s):
     return (v - 1) // s + 1
 
@@ -277,7 +286,10 @@ class ResNetFn(Function):
             s, planes = blk["stride"], blk["planes"]
             a = a_next if a_next is not None else conv1x1(cur, blk["c1"]["w"], blk["c1"]["b"], new(planes, hh, ww), RELU)   # conv1 + bn1 + relu
             ho, wo = _half(hh, s), _half(ww, s)
-            b = K.conv3x3(a, blk["c2"]["w"], blk["c2"]["b"], new(planes, ho, wo), s, RELU)      # conv2 (stride here) + bn2 + relu
+            if s == 1 and K.conv3x3_small_supported(a, planes):                                 # layer3 / layer4: small-image kernel, chunk-major weights
+                b = K.conv3x3_small(a, _chunked(blk["c2"], "w"), blk["c2"]["b"], new(planes, ho, wo), RELU)
+            else:
+                b = K.conv3x3(a, blk["c2"]["w"], blk["c2"]["b"], new(planes, ho, wo), s, RELU)  # conv2 (stride here) + bn2 + relu
             if blk["ds"] is not None:                                                           # downsample: conv1x1 stride s + bn
                 idn = conv1x1(cur, blk["ds"]["w"], blk["ds"]["b"], new(planes * EXPANSION, ho, wo), NONE, in_stride=s)
             else:
@@ -323,7 +335,9 @@ class ResNetFn(Function):
             # g: gradient of this block's output, already gated by its final ReLU
             gb = gb_pre if gb_pre is not None else conv1x1(g, blk["c3"]["wt"], None, new(planes, b.shape[2], b.shape[3]), NONE, egate=b, egate_act=RELU)
             ga = new(planes, a.shape[2], a.shape[3])
-            if s == 1:
+            if s == 1 and K.conv3x3_small_supported(gb, planes):
+                K.conv3x3_small(gb, _chunked(blk["c2"], "wd"), None, ga, egate=a, egate_act=RELU)
+            elif s == 1:
                 K.conv3x3(gb, blk["c2"]["wd"], None, ga, egate=a, egate_act=RELU)
             else:
                 K.conv3x3_s2_dgrad(gb, blk["c2"]["wd"], ga, egate=a, egate_act=RELU)
