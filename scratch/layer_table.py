@@ -65,7 +65,7 @@ def main():
     layers = [("down1.2", 64, 64, S, "pool"), ("down2.0", 64, 128, S // 2, "bits"), ("down2.2", 128, 128, S // 2, "pool"),
               ("down3.0", 128, 256, S // 4, "bits"), ("down3.2", 256, 256, S // 4, "pool"), ("down4.0", 256, 512, S // 8, "bits"),
               ("down4.2", 512, 512, S // 8, "plain"), ("up3.0", 768, 256, S // 4, "bits"), ("up3.2", 256, 256, S // 4, "plain"),
-              ("up2.0", 384, 128, S // 2, "bits"), ("up2.2", 128, 128, S // 2, "plain"), ("up1.0", 192, 64, S, "bits"), ("up1.2", 64, 64, S, "plain")]
+              ("up2.0", 384, 128, S // 2, "bits"), ("up2.2", 128, 128, S // 2, "plain"), ("up1.0", 192, 64, S, "bits"), ("up1.2", 64, 64, S, "head")]
     # TWO passes over the list, the second one reported: whatever the table measures first reads 10-25 % slow (r04: down1.2 forward 205 us
     # as the first row against 151-163 us for the same kernel on the same inputs later in the process, warm-up launches of another shape
     # notwithstanding -- profiles/r04_down12_probe.txt); the first pass's numbers are printed to the log for comparison
@@ -86,6 +86,10 @@ def main():
           elif kind == "bits":
               gbo = K.gate_bits_alloc(y)
               t_f = run(lambda: K.conv3x3_bits(x, wf, bias, y, 1, gate_bits_out=gbo))
+          elif kind == "head":                                            # round 4: the 1x1 head + tanh rides in this conv's epilogue
+              hw3, hb3 = torch.rand((3, 64), device=dev) - 0.5, torch.zeros(3, device=dev)
+              himg = torch.empty((B, 3, s, s), device=dev)
+              t_f = run(lambda: K.conv3x3_relu_head(x, wf, bias, y, hw3, hb3, himg))
           else:
               t_f = run(lambda: K.conv3x3(x, wf, bias, y, 1, 1))
           if kind == "bits":
@@ -142,7 +146,7 @@ def main():
     g("conv3x3_c3_wgrad 3->64", run(lambda: K.conv3x3_c3_wgrad(xi, gy, dw, db, 1, 1)), img + a64)
     w3, b3 = torch.rand((3, 64), device=dev) - 0.5, torch.zeros(3, device=dev)
     out = torch.empty((B, 3, S, S), device=dev)
-    g("conv1x1_tanh_fwd 64->3", run(lambda: K.conv1x1_tanh(y, w3, b3, out)), a64 + img)
+    t_head_alone = run(lambda: K.conv1x1_tanh(y, w3, b3, out))       # not in the step any more (fused into up1.2's forward): reported, not summed
     dxx = empty_nhwc(B, 64, S, S, bf, dev)
     dw3, db3 = torch.zeros((3, 64), device=dev), torch.zeros(3, device=dev)
     g("conv1x1_tanh_bwd 64->3 (ReLU-gated dx)", run(lambda: K.conv1x1_tanh_bwd(out, out, y, w3, dxx, dw3, db3, 1)), 2 * img + 2 * a64)
@@ -151,7 +155,7 @@ def main():
     path = os.path.join(root, "gpurun_out", f"{tag}_layer_table.md")
     with open(path, "w") as fh:
         fh.write(f"# {tag}: per-layer kernel table, cUNet {S}x{S} bf16 B={B}, every kernel stand-alone (median of 7 x (4 back-to-back launches / 4), hipEvents)\n\n")
-        fh.write("MFMA convs (peak 2500 TFLOP/s dense bf16): forward = conv+bias+ReLU (+fused 2x2 max-pool and gate / arg-max bits on the encoder blocks' second conv); "
+        fh.write("MFMA convs (peak 2500 TFLOP/s dense bf16): forward = conv+bias+ReLU (+fused 2x2 max-pool and gate / arg-max bits on the encoder blocks' second conv; up1.2: + the 64->3 head + tanh from its epilogue); "
                  "dgrad = data gradient as the fused graph launches it (gate bits of the block's first-conv output in the epilogue for *.2, ungated for *.0); wgrad = weight+bias gradient incl. its split-K reducer.\n\n")
         fh.write("| layer | shape | GFLOP | fwd us | fwd TFLOP/s | dgrad us | dgrad TFLOP/s | wgrad us | wgrad TFLOP/s |\n|---|---|---|---|---|---|---|---|---|\n")
         for r in rows_conv:
@@ -164,6 +168,8 @@ def main():
         for r in rows_glue:
             fh.write(f"| {r[0]} | {r[1]:.1f} | {r[2]:.0f} | {r[3]:.0f} | {r[3] / 80:.0f} % |\n")
         fh.write(f"| **sum** | {sum(r[1] for r in rows_glue):.0f} | | | |\n")
+        fh.write(f"\nThe 64->3 head + tanh forward is part of up1.2's forward launch above (conv3x3_mfma_v2 GATED = 5); the stand-alone head kernel it replaces in the "
+                 f"step (fp32 / narrow-image fallback) measures {t_head_alone:.1f} us here.\n")
     print(open(path).read())
 
 
