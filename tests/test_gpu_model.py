@@ -165,7 +165,12 @@ def test_cunet_fused_graph_equals_per_layer_functions(precision):
         out = net(xd, c.to(DEV))
         torch.mean(torch.abs(out - xd)).backward()
         res.append((out.detach(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
-    assert torch.equal(res[0][0], res[1][0])
+    if precision == "fp32":
+        assert torch.equal(res[0][0], res[1][0])
+    else:
+        # round 4: the fused graph computes the 64 -> 3 head + tanh in the last conv's epilogue on the matrix cores (same stored bf16
+        # activations, fp32-exact products, another summation order than the stand-alone head kernel of the per-layer path)
+        assert (res[0][0] - res[1][0]).abs().max().item() < 2e-6
     assert set(res[0][1]) == set(res[1][1]) and len(res[0][1]) == 36
     for k in res[0][1]:
         a, b = res[0][1][k].double().reshape(-1), res[1][1][k].double().reshape(-1)
