@@ -596,3 +596,15 @@ def test_small_image_conv_vs_generic_and_fp32(case):
     scale = max(1.0, ref.abs().max().item())
     assert (res[1] - res[0]).abs().max().item() <= 2 * scale * 2.0 ** -8
     assert (res[1] - ref).abs().max().item() <= scale * 2.0 ** -8 + 1e-6
+
+
+def test_dropout_masks_equal_the_numpy_restatement_of_the_hash():
+    """wu_dropout_mask (and with it every kernel that draws keep bits: they share wu_rand4) against tests/_dropout_hash.py, bit for bit --
+    the statistics pinned on the CPU (tests/test_host_cpu.py::test_dropout_hash_statistics) are the kernels' statistics."""
+    import numpy as np
+    from _dropout_hash import keep_mask_nchw
+    from wu import functional as WF
+    dev = _dev()
+    for (n, c, h, w, p, seed) in ((2, 128, 12, 20, 0.3, 133), (1, 512, 8, 8, 0.3, (99 * 4 + 3) & 0x7FFFFFFFFFFFFFFF), (3, 64, 6, 10, 0.5, (1 << 40) + 7)):
+        got = WF.dropout_mask(n, c, h, w, p, seed, dev).cpu().numpy()
+        assert np.array_equal(got, keep_mask_nchw(n, c, h, w, p, seed)), (n, c, h, w, p, seed)

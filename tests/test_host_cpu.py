@@ -203,3 +203,51 @@ def test_bf16_sum_order_witness():
             assert 0.9 <= ee, (k, ee)
             deep.append(ee)
     assert len(deep) == 28 and min(deep) <= 0.98 and max(deep) <= 0.9975      # the amplification is there, on every deep layer
+
+
+def test_dropout_hash_statistics():
+    """The dropout keep decisions (cunet.py:61,68,75: nn.Dropout(0.3)) come from a counter hash of (seed, element group): the splitmix64
+    finaliser, 16 bits per element.  Pinned on the numpy restatement (tests/_dropout_hash.py; the GPU test pins the kernels to it bit for
+    bit): keep rate of each 16-bit field, its histogram, independence of the four fields of a draw, of neighbouring groups (lag 1 and one
+    384-channel pixel) and of ADJACENT seeds (the three dropout layers of a step use seeds 4 s + 1, 2, 3).  The cheaper candidate measured
+    in round 4 (rand4_cheap: as good statistically, not faster on the GPU, not shipped) goes through the same checks."""
+    import numpy as np
+    from _dropout_hash import rand4, rand4_cheap, keep_thr
+    for rand4 in (rand4, rand4_cheap):
+        _check_dropout_hash(rand4, keep_thr)
+
+
+def _check_dropout_hash(rand4, keep_thr):
+    import numpy as np
+    n = 1 << 22
+    g = np.arange(n, dtype=np.uint64)
+    thr = keep_thr(0.3)
+    assert thr == 45875
+    sig_rate, sig_corr = (0.21 / n) ** 0.5, n ** -0.5
+
+    def fields(r):
+        return [((r >> np.uint64(16 * e)) & np.uint64(0xFFFF)).astype(np.int64) for e in range(4)]
+
+    keeps = {}
+    for seed in (0, 133, 134, 135, (1 << 40) + 7):
+        f = fields(rand4(seed, g))
+        k = [(x < thr).astype(np.float64) for x in f]
+        keeps[seed] = k
+        for e in range(4):
+            assert abs(k[e].mean() - thr / 65536.0) < 5 * sig_rate, (seed, e, k[e].mean())
+            h = np.bincount(f[e] >> 6, minlength=1024)
+            chi2 = float(((h - n / 1024) ** 2 / (n / 1024)).sum())
+            assert abs(chi2 - 1023) < 6 * (2 * 1023) ** 0.5, (seed, e, chi2)
+        for i in range(4):
+            for j in range(4):
+                if j < i:
+                    assert abs(np.corrcoef(k[i], k[j])[0, 1]) < 5 * sig_corr
+                assert abs(np.corrcoef(k[i][:-1], k[j][1:])[0, 1]) < 5 * sig_corr          # the next group
+                assert abs(np.corrcoef(k[i][:-96], k[j][96:])[0, 1]) < 5 * sig_corr        # the same channels of the next pixel (C = 384)
+    for a, b in ((133, 134), (134, 135), (0, 133)):
+        for e in range(4):
+            assert abs(np.corrcoef(keeps[a][e], keeps[b][e])[0, 1]) < 5 * sig_corr, (a, b, e)
+    # every output bit is fair
+    r = rand4(7, g)
+    for bit in range(64):
+        assert abs(float(((r >> np.uint64(bit)) & np.uint64(1)).mean()) - 0.5) < 5 * 0.5 * sig_corr, bit
