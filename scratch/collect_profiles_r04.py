@@ -9,9 +9,11 @@ for a, b in (("r04_pmc.json", "r04_pmc.json"), ("r04_pmc.md", "r04_pmc.md"), ("r
              ("r04_gan_cls_kernel_table.txt", "r04_gan_cls_kernel_table.txt"), ("r04_gan_est_kernel_table.txt", "r04_gan_est_kernel_table.txt")):
     if os.path.exists(os.path.join(G, a)):
         shutil.copy(os.path.join(G, a), os.path.join(P, b))
-with open(os.path.join(P, "r04_other_workloads.jsonl"), "w") as fh:
-    for f in ("gan_cls_standin", "gan_cls_resnet", "gan_est_resnet_b64", "infer512_graph", "infer512_graph_dropout"):
-        fh.write([l for l in open(os.path.join(G, f"r04_{f}.json")) if l.startswith("{")][-1])
+OTHER = ("gan_cls_standin", "gan_cls_resnet", "gan_est_resnet_b64", "infer512_graph", "infer512_graph_dropout")
+if all(os.path.exists(os.path.join(G, f"r04_{f}.json")) for f in OTHER):      # a call that ran the bench / trace / PMC legs only leaves the committed lines alone
+    with open(os.path.join(P, "r04_other_workloads.jsonl"), "w") as fh:
+        for f in OTHER:
+            fh.write([l for l in open(os.path.join(G, f"r04_{f}.json")) if l.startswith("{")][-1])
 d = json.loads([l for l in open(os.path.join(P, "r04_bench_default.json")) if l.startswith("{")][-1])
 p = json.loads([l for l in open(os.path.join(G, "r04final_bench.log")) if l.startswith("{")][-1])
 rows = list(csv.DictReader(open(os.path.join(P, "r04_bench_b32_bf16_kernel_stats.csv"))))
