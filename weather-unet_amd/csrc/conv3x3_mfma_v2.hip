@@ -17,6 +17,10 @@
 #include "wu_common.h"
 #include "conv_internal.h"
 
+#ifndef WU_CONV_STORE_AUX
+#define WU_CONV_STORE_AUX 0
+#endif
+
 namespace {
 
 struct K {
@@ -318,7 +322,19 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma_v2_kernel(const V2Args a
     auto store_ov = [&](int k) __attribute__((always_inline)) {
         // k = ((mp * 2 + ni) * 2 + gp) * 2 + r  ->  row 2 mp + r, channels + 32 ni + 16 gp
         const int r = k & 1, gp = (k >> 1) & 1, ni = (k >> 2) & 1, mp = k >> 3;
+#if WU_CONV_STORE_AUX
+        // experiment (scratch/ab_unet_lib.sh): the same 16-byte stores through a buffer descriptor with cache-policy bits (aux 16 = sc1, write-through: no dirty
+        // lines left in the XCD L2s for the end-of-kernel write-back; 2 = nt)
+        if ((ov_ok >> k) & 1u) {
+            const unsigned long long u = (unsigned long long)(uintptr_t)ov_img;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffull)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, ov[k]), rs,
+                                                   (int)(ov_off + (unsigned)(2 * mp + r) * ov_row + (unsigned)(64 * ni + 32 * gp)), 0, WU_CONV_STORE_AUX);
+        }
+#else
         if ((ov_ok >> k) & 1u) *(uint4*)((char*)ov_img + (ov_off + (unsigned)(2 * mp + r) * ov_row + (unsigned)(64 * ni + 32 * gp))) = ov[k];
+#endif
     };
     Tc cur = decode(t_begin), fetch = cur;
     set_fetch_tile(fetch);
