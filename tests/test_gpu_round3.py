@@ -254,13 +254,15 @@ def test_full_size_gan_iteration_is_deterministic(mode, batch):
     # sharing and the fence-less ordering events switched off.  A missing wait or a stale operand that repeats run to run (the
     # cross-stream hazard of DESIGN.md 4 was 10 of 10) passes the two-run comparison above; it cannot pass this one.
     from wu import train_step as TS, unet_graph as UG
-    saved = (TS.OVERLAP_D_PASSES, TS.OVERLAP_D_WITH_ESTIMATOR, TS.SHARE_ENCODER, UG.LIGHT_EVENTS)
+    # (also off in the plain order: the hipGraph replay of the estimator's no-grad pass, so the replay is compared with the eager launches)
+    assert st._est_graphs and all(g.replays >= 2 for g in st._est_graphs.values()), "the estimator's no-grad pass did not run from its hipGraph"
+    saved = (TS.OVERLAP_D_PASSES, TS.OVERLAP_D_WITH_ESTIMATOR, TS.SHARE_ENCODER, UG.LIGHT_EVENTS, TS.GRAPH_ESTIMATOR)
     try:
-        TS.OVERLAP_D_PASSES = TS.OVERLAP_D_WITH_ESTIMATOR = TS.SHARE_ENCODER = False
+        TS.OVERLAP_D_PASSES = TS.OVERLAP_D_WITH_ESTIMATOR = TS.SHARE_ENCODER = TS.GRAPH_ESTIMATOR = False
         UG.LIGHT_EVENTS = False
         l3, g3, b3 = _iteration(st, images, rand_images, d_state)
     finally:
-        TS.OVERLAP_D_PASSES, TS.OVERLAP_D_WITH_ESTIMATOR, TS.SHARE_ENCODER, UG.LIGHT_EVENTS = saved
+        TS.OVERLAP_D_PASSES, TS.OVERLAP_D_WITH_ESTIMATOR, TS.SHARE_ENCODER, UG.LIGHT_EVENTS, TS.GRAPH_ESTIMATOR = saved
     assert l1 == l3, f"losses differ between the overlapped and the plain order: {l1} vs {l3}"
     for k in g1:
         assert torch.equal(g1[k], g3[k]), f"gradient of {k}: overlapped order != plain order"

@@ -608,3 +608,64 @@ def test_dropout_masks_equal_the_numpy_restatement_of_the_hash():
     for (n, c, h, w, p, seed) in ((2, 128, 12, 20, 0.3, 133), (1, 512, 8, 8, 0.3, (99 * 4 + 3) & 0x7FFFFFFFFFFFFFFF), (3, 64, 6, 10, 0.5, (1 << 40) + 7)):
         got = WF.dropout_mask(n, c, h, w, p, seed, dev).cpu().numpy()
         assert np.array_equal(got, keep_mask_nchw(n, c, h, w, p, seed)), (n, c, h, w, p, seed)
+
+
+def test_graphed_estimator_pass_is_bitwise_the_eager_pass():
+    """The frozen estimator's no-grad pass (t_cls_train.py:424,297,237) replayed from a hipGraph (wu.resnet.GraphedEstimatorPass, what
+    WeatherTransferStep.step() runs): raw outputs bit-equal to the eager launches for two different batches through ONE capture (the captured
+    kernels read the static input, nothing of the warm-up data survives), the static output is not aliased by what the call returns, a wrong
+    batch shape raises, and a moved estimator state (load_state_dict) is reported stale."""
+    from wu.resnet import GraphedEstimatorPass, ResNet101Estimator
+    DEV = _dev()
+    torch.manual_seed(3)
+    est = ResNet101Estimator(num_classes=5, precision="bf16").to(DEV)
+    a, b = torch.randn(3, 3, 64, 64, device=DEV), torch.randn(3, 3, 64, 64, device=DEV)
+    g = GraphedEstimatorPass(est, (6, 3, 64, 64))
+    with torch.no_grad():
+        e1 = est(torch.cat([a, b]))
+        e2 = est(torch.cat([b, a]))
+    r1 = g((a, b))
+    r2 = g((b, a))
+    torch.cuda.synchronize()
+    assert torch.isfinite(e1).all() and (e1 != e2).any()
+    assert torch.equal(r1, e1) and torch.equal(r2, e2), "graph replay differs from the eager pass"
+    assert r1.data_ptr() != g.out.data_ptr()
+    with pytest.raises(ValueError):
+        g((a,))
+    with pytest.raises(ValueError):
+        g((a, torch.randn(3, 3, 32, 64, device=DEV)))
+    assert not g.stale()
+    sd = {k: v.clone() for k, v in est.state_dict().items()}
+    sd["fc.bias"] = sd["fc.bias"] + 1
+    est.load_state_dict(sd)
+    assert g.stale()
+
+
+def test_graphed_estimator_grad_pass_is_bitwise_the_eager_node():
+    """The estimator's DIFFERENTIATED forward (t_cls_train.py:247-250) replayed from a hipGraph with its activations in the graph's static
+    buffers (wu.resnet.GraphedEstimatorGradPass) and the eager backward on them: raw outputs and the input gradient bit-equal to the eager
+    autograd node, for two different inputs through one capture; a second replay before the first one's backward makes that backward raise
+    instead of differentiating through overwritten activations."""
+    from wu.resnet import GraphedEstimatorGradPass, ResNet101Estimator
+    DEV = _dev()
+    torch.manual_seed(4)
+    est = ResNet101Estimator(num_classes=5, precision="bf16").to(DEV)
+    g = GraphedEstimatorGradPass(est, (4, 3, 64, 96))
+    tgt = torch.randn(4, 5, device=DEV)
+    for seed in (1, 2):
+        x0 = _rand((4, 3, 64, 96), seed).to(DEV)
+        xe = x0.clone().requires_grad_(True)
+        ye = est(xe)
+        ((ye - tgt) ** 2).sum().backward()
+        xg = x0.clone().requires_grad_(True)
+        yg = g(xg)
+        ((yg - tgt) ** 2).sum().backward()
+        torch.cuda.synchronize()
+        assert torch.equal(yg, ye), "graphed forward differs from the eager node"
+        assert xg.grad is not None and xg.grad.abs().max().item() > 0
+        assert torch.equal(xg.grad, xe.grad), "input gradient through the graphed pass differs from the eager node"
+    xa = _rand((4, 3, 64, 96), 7).to(DEV).requires_grad_(True)
+    ya = g(xa)
+    g(_rand((4, 3, 64, 96), 8).to(DEV).requires_grad_(True))
+    with pytest.raises(RuntimeError, match="replayed again"):
+        ya.sum().backward()

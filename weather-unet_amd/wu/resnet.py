@@ -246,6 +246,116 @@ class ResNet101Estimator(nn.Module):
         return torch.nn.functional.linear(feat, self.fc.weight, self.fc.bias)
 
 
+class GraphedEstimatorPass:
+    """hipGraph replay of the frozen estimator's NO-GRAD pass over a static batch shape (t_cls_train.py:424,297,237: ``self.estimator(images)``
+    under ``torch.no_grad()``): ~330 kernel launches per pass become one graph launch from the host (the GAN iteration's enqueue time was 56-81 %
+    of its wall time, profiles/r04_gan_phase_times.txt; every launcher of the library is capture-safe, include/wu_kernels.h).  The same kernels
+    in the same order on the same stream: results are bit-identical to the eager pass (tests/test_gpu_round4.py).
+
+        g = GraphedEstimatorPass(est, (2 * B, 3, 256, 256))
+        raw = g((rand_images, images))          # parts are copied into the static input one after the other along the batch
+
+    The captured kernels read the folded / packed operands of ``est.plan()`` that existed at capture time: the pass keeps that plan alive and
+    ``stale()`` says when the estimator's state has moved (load_state_dict, a broadcast): the caller captures again."""
+
+    def __init__(self, est, shape, warmup=2):
+        dev = next(est.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedEstimatorPass needs the estimator on a GPU")
+        self.est, self.shape = est, tuple(shape)
+        self.x = torch.zeros(self.shape, dtype=torch.float32, device=dev)
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):         # first-use work (BatchNorm folding, chunk-major weights, kernel attributes) must not be captured
+                est(self.x)
+        cur.wait_stream(side)
+        self.key = est._state_key()
+        self._plan = est._plan              # the captured kernels hold raw pointers into these tensors
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.out = est(self.x)
+        self.replays = 0
+
+    def stale(self):
+        return self.est._state_key() != self.key
+
+    def __call__(self, parts):
+        if isinstance(parts, torch.Tensor):
+            parts = (parts,)
+        o = 0
+        for t in parts:
+            if tuple(t.shape[1:]) != self.shape[1:]:
+                raise ValueError(f"GraphedEstimatorPass: captured for {self.shape}, got a part of shape {tuple(t.shape)}")
+            self.x[o:o + t.shape[0]].copy_(t)
+            o += t.shape[0]
+        if o != self.shape[0]:
+            raise ValueError(f"GraphedEstimatorPass: captured for a batch of {self.shape[0]}, got {o} images")
+        self.graph.replay()
+        self.replays += 1
+        return self.out.clone()             # the static output is overwritten by the next replay
+
+
+class _GraphedResNetFn(Function):
+    """One replay of a GraphedEstimatorGradPass as an autograd node: forward = copy + graph launch, backward = ResNetFn.backward (eager) on the
+    activations the replay left in the graph's static buffers."""
+
+    @staticmethod
+    def forward(ctx, x, holder):
+        holder.x.copy_(x)
+        holder.graph.replay()
+        holder.replays += 1
+        ctx.plan, ctx.code, ctx.saved, ctx.stem, ctx.amax, ctx.xshape = holder.state
+        ctx.holder, ctx.rid = holder, holder.replays
+        return holder.feat.clone()
+
+    @staticmethod
+    def backward(ctx, gfeat):
+        if ctx.holder.replays != ctx.rid:
+            raise RuntimeError("GraphedEstimatorGradPass: the pass was replayed again before this backward ran -- its saved activations are "
+                               "gone (one forward, then its backward; use the eager estimator for several live forwards)")
+        return ResNetFn.backward(ctx, gfeat)[0], None
+
+
+class GraphedEstimatorGradPass:
+    """hipGraph replay of the frozen estimator's DIFFERENTIATED forward (t_cls_train.py:247-250: ``self.estimator_(fake_out)`` with the
+    generator's graph attached) over a static batch shape.  The forward launches are captured with every activation the backward needs
+    written into the graph's static buffers; a call copies the input in, replays, and returns raw outputs whose autograd node runs the usual
+    eager backward on those buffers.  One live forward at a time: a second replay before the first one's backward raises in that backward.
+    Bit-identical to the eager node (tests/test_gpu_round4.py)."""
+
+    def __init__(self, est, shape, warmup=2):
+        dev = next(est.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedEstimatorGradPass needs the estimator on a GPU")
+        self.est, self.shape = est, tuple(shape)
+        self.x = torch.zeros(self.shape, dtype=torch.float32, device=dev)
+        code = precision_code(est.precision)
+        plan = est.plan()
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                ResNetFn.body(self.x, plan, code, True)
+        cur.wait_stream(side)
+        self.key = est._state_key()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.feat, self.state = ResNetFn.body(self.x, plan, code, True)
+        self.replays = 0
+
+    def stale(self):
+        return self.est._state_key() != self.key
+
+    def __call__(self, x):
+        if tuple(x.shape) != self.shape:
+            raise ValueError(f"GraphedEstimatorGradPass: captured for {self.shape}, got {tuple(x.shape)}")
+        feat = _GraphedResNetFn.apply(x, self)
+        return torch.nn.functional.linear(feat, self.est.fc.weight, self.est.fc.bias)
+
+
 # ----------------------------------------------------------------------------------------------
 # the network body as one autograd node
 # ----------------------------------------------------------------------------------------------
@@ -265,11 +375,18 @@ def _half(v, s):
 class ResNetFn(Function):
     @staticmethod
     def forward(ctx, x, plan, code):
+        feat, state = ResNetFn.body(x, plan, code, ctx.needs_input_grad[0])
+        if state is not None:
+            ctx.plan, ctx.code, ctx.saved, ctx.stem, ctx.amax, ctx.xshape = state
+        return feat
+
+    @staticmethod
+    def body(x, plan, code, keep):
+        """The forward launches; ``keep``: also return what backward needs (plan, code, per-block activations, stem, pool arg-max, input shape)."""
         dt, dev = torch_dtype(code), x.device
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
         n, _, h, w = x.shape
-        keep = ctx.needs_input_grad[0]
 
         def new(c, hh, ww):
             return empty_nhwc(n, c, hh, ww, dt, dev)
@@ -308,9 +425,7 @@ class ResNetFn(Function):
         feat = torch.empty((n, cur.shape[1]), dtype=torch.float32, device=dev)
         _lib.call("wu_sumpool_fwd", cur.data_ptr(), nhwc_ld(cur), feat.data_ptr(), n, hh, ww, cur.shape[1], code, stream_ptr())
         feat.mul_(1.0 / (hh * ww))                                                              # adaptive_avg_pool2d(1)
-        if keep:
-            ctx.plan, ctx.code, ctx.saved, ctx.stem, ctx.amax, ctx.xshape = plan, code, saved, stem, amax, tuple(x.shape)
-        return feat
+        return feat, ((plan, code, saved, stem, amax, tuple(x.shape)) if keep else None)
 
     @staticmethod
     def backward(ctx, gfeat):

@@ -49,6 +49,8 @@ OVERLAP_D_PASSES = os.environ.get("WU_GAN_OVERLAP_D", "1") == "1"
 OVERLAP_D_WITH_REDUCER = os.environ.get("WU_GAN_OVERLAP_D_DDP", "1") == "1"
 # step(): the generator's encoder once per iteration instead of twice (A/B switch)
 SHARE_ENCODER = os.environ.get("WU_GAN_SHARE_ENCODER", "1") == "1"
+# step(): the frozen ResNet-101 estimator's no-grad pass over cat(rand_images, images) replayed from a hipGraph (A/B switch; bit-identical)
+GRAPH_ESTIMATOR = os.environ.get("WU_GAN_GRAPH_EST", "1") == "1"
 # with a pass on the second stream, a parameter's AccumulateGrad node (created on the main stream) receives gradients produced on the
 # other one: autograd synchronises the two correctly and says so once per backward (a note about CUDA-graph capture, not an error)
 warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
@@ -96,6 +98,7 @@ class WeatherTransferStep:
         self.estimator_ = (estimator if estimator is not None else StandInEstimator(num_classes)).to(dev).eval()
         for p in self.estimator_.parameters():
             p.requires_grad_(False)
+        self._est_graphs = {}           # batch shape -> GraphedEstimatorPass (step(): the estimator's no-grad pass)
         self.inference.train()
         self.discriminator.train()
         wd = lr / 20
@@ -107,6 +110,36 @@ class WeatherTransferStep:
             self.g_red = GradBucketReducer(ready_order(self.inference), bucket_mb=12.0, ready_order=True).attach(self.inference)
             self.d_red = GradBucketReducer(list(self.discriminator.parameters()), bucket_mb=12.0)
             broadcast_buffers(self.discriminator)      # SN weight_u / weight_v identical on every rank
+
+    def _estimator_nograd(self, rand_images, images):
+        """estimator_(cat(rand_images, images)) under no_grad.  The HIP ResNet-101 on fp32 device images: one hipGraph replay per iteration
+        (wu.resnet.GraphedEstimatorPass, captured per batch shape, again when the estimator's state moves); anything else: the eager call."""
+        from wu.resnet import GraphedEstimatorPass, ResNet101Estimator
+        est = self.estimator_
+        if not (GRAPH_ESTIMATOR and isinstance(est, ResNet101Estimator) and images.is_cuda and images.dtype == torch.float32
+                and rand_images.dtype == torch.float32 and images.shape[1:] == rand_images.shape[1:]
+                and not torch.cuda.is_current_stream_capturing()):
+            return est(torch.cat([rand_images, images]))
+        shape = (rand_images.shape[0] + images.shape[0],) + tuple(images.shape[1:])
+        g = self._est_graphs.get(shape)
+        if g is None or g.stale():
+            g = self._est_graphs[shape] = GraphedEstimatorPass(est, shape)
+        return g((rand_images, images))
+
+    def _estimator_grad(self, x):
+        """estimator_(x) with the generator's graph attached (t_cls_train.py:247-250).  The HIP ResNet-101: forward replayed from a hipGraph
+        whose static buffers hold the activations, eager backward (wu.resnet.GraphedEstimatorGradPass; update_inference has exactly one such
+        forward alive per iteration); anything else: the eager call."""
+        from wu.resnet import GraphedEstimatorGradPass, ResNet101Estimator
+        est = self.estimator_
+        if not (GRAPH_ESTIMATOR and isinstance(est, ResNet101Estimator) and x.is_cuda and x.dtype == torch.float32 and x.requires_grad
+                and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()):
+            return est(x)
+        key = ("grad",) + tuple(x.shape)
+        g = self._est_graphs.get(key)
+        if g is None or g.stale():
+            g = self._est_graphs[key] = GraphedEstimatorGradPass(est, tuple(x.shape))
+        return g(x)
 
     def _d_stream(self, dev):
         """The probed second stream of the fused U-Net graph (a stream that really runs beside the current one: HIP maps streams
@@ -205,10 +238,11 @@ class WeatherTransferStep:
         finally:
             for p in d_params:
                 p.requires_grad_(True)
+        raw_fake = self._estimator_grad(fake_out)
         if self.cross_ent:
-            fake_c_out = self.estimator_(fake_out)                                       # :248 last layer is not softmax
+            fake_c_out = raw_fake                                                        # :248 last layer is not softmax
         else:
-            fake_c_out = self.estimator(fake_out)                                        # :250
+            fake_c_out = torch.softmax(raw_fake, dim=1) if self.mode == "cls" else raw_fake   # :250 (self.estimator: softmax head in t_cls_train)
             r_labels_ = r_labels                                                         # :251
         if side is not None:
             main.wait_stream(side)
@@ -239,7 +273,7 @@ class WeatherTransferStep:
         else:
             with torch.no_grad():
                 # estimator(rand_images) (:424) and estimator(images) (:297, :237) in one pass over the concatenated batch
-                raw_all = self.estimator_(torch.cat([rand_images, images]))
+                raw_all = self._estimator_nograd(rand_images, images)
                 raw, raw_img = raw_all[:rand_images.shape[0]], raw_all[rand_images.shape[0]:]
                 rand_labels = torch.softmax(raw, dim=1) if self.mode == "cls" else raw   # :423
                 pred_labels = torch.softmax(raw_img, dim=1) if self.mode == "cls" else raw_img
