@@ -383,15 +383,21 @@ def test_gan_step_matches_oracle(mode, supervised, cross_ent):
 def test_gan_step_bf16(mode, size):
     """The same two steps in the bf16 production mode (configs[2] / configs[3] arithmetic).  Tolerances: losses within 5e-2
     relative (north_star's bf16 forward tolerance; the hinge / reconstruction terms are means of O(1) values), D gradients
-    cosine >= 0.98, G gradients cosine >= 0.9 (they cross D, the estimator and ~30 bf16-rounded gated ops; the per-layer
-    figures are printed; the tight bf16 check of G's own backward is test_bf16_gradients_vs_emulating_oracle)."""
+    cosine >= 0.995 (measured 0.9976-0.9983; D has no normalisation layer), G gradients cosine >= 0.94 (measured 0.959 / 0.978 /
+    0.980: they cross D, the estimator and the three AdaIN boundaries, whose instance-norm backward amplifies one-ulp bf16 flips --
+    two bf16 emulations that differ only in fp32 summation order already disagree by 0.951 on those layers,
+    tests/test_host_cpu.py::test_bf16_sum_order_witness; the gradients downstream of the last AdaIN are at 0.9999+).  The per-layer
+    figures are printed; the tight bf16 checks of the kernels' own backward arithmetic are the stage-by-stage tests
+    (test_bf16_backward_stage_by_stage_vs_emulating_oracle: cos >= 0.99999; test_estimator_bf16_backward_block_by_block: >= 0.9999)."""
     r = _gan_case(mode, "bf16", size=size)            # size 256 = BASELINE configs[2]'s resolution (B=2: the CPU oracle's budget)
     print(f"bf16 GAN step {mode} {size}x{size}: d_loss err {r['d_loss_err']:.2e}, g_loss err {r['g_loss_err']:.2e}, worst D cos {r['worst_d']:.5f}, "
           f"worst G cos {r['worst_g']:.5f}")
     for k, v in r["per_layer"].items():
         print(f"   {k:24s} cos {v:.5f}")
     assert r["d_loss_err"] <= 5e-2 and r["g_loss_err"] <= 5e-2
-    assert r["worst_d"] >= 0.98 and r["worst_g"] >= 0.9
+    assert r["worst_d"] >= 0.995 and r["worst_g"] >= 0.94
+    tail = [v for k, v in r["per_layer"].items() if k.startswith(("dconv_up1", "conv_last"))]
+    assert tail and min(tail) >= 0.999, "gradients downstream of the last AdaIN boundary"
 
 
 def test_checkpoint_interchange_and_class_sweep(tmp_path):

@@ -127,7 +127,7 @@ def _est(nc, seed, precision, layers):
 def test_resnet_forward_and_input_gradient(precision, layers, shape):
     """Outputs, stage activations' effect and the gradient wrt the INPUT image (the only gradient the GAN loop needs from the
     estimator) against the oracle restatement.  fp32: <= 1e-3 relative; bf16: <= 5e-2 relative on the outputs (north_star's bf16
-    tolerance, relative to the output scale), input-gradient cosine >= 0.9 (33 blocks of bf16-rounded, ReLU-gated gradients)."""
+    tolerance, relative to the output scale), input-gradient cosine >= 0.975 (measured 0.9898-0.9902; 33 blocks of bf16-rounded, ReLU-gated gradients)."""
     nc, seed = 5, 3
     net, sd = _est(nc, seed, precision, layers)
     n, h, w = shape
@@ -148,7 +148,7 @@ def test_resnet_forward_and_input_gradient(precision, layers, shape):
     if precision == "fp32":
         assert err <= 1e-3 and cos >= 0.9999 and rel <= 1e-2
     else:
-        assert err <= 5e-2 and cos >= 0.9
+        assert err <= 5e-2 and cos >= 0.975
     with torch.no_grad():
         assert torch.equal(net(xd.detach()), out.detach())        # the no_grad path (3 of the 4 calls per iteration) is the same forward
 

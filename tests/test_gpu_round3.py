@@ -308,7 +308,9 @@ def test_full_size_sndisc_production_vs_generic():
 
 def test_full_size_estimator_production_vs_generic():
     """The frozen ResNet-101 (classifier.py:106-112) at 256x256, B=4: bf16 production kernels (1x1 GEMMs, MFMA 3x3, stem, pools)
-    against the fp32 kernels on the same folded weights: outputs within 5e-2 of their scale, input-gradient cosine >= 0.95;
+    against the fp32 kernels on the same folded weights: outputs within 5e-2 of their scale, input-gradient cosine >= 0.975 (measured
+    0.9847-0.988: the bf16 precision mode over 33 gated blocks -- block by block the HIP path agrees with a bf16 emulation at >= 0.9999,
+    tests/test_gpu_round4.py::test_estimator_bf16_backward_block_by_block);
     B=32 forward run twice is bitwise identical and equals the B=4 slice rows to bf16 accuracy."""
     from wu.resnet import ResNet101Estimator
     nc = 5
@@ -329,7 +331,7 @@ def test_full_size_estimator_production_vs_generic():
     err = (res["bf16"][0] - res["fp32"][0]).abs().max().item() / scale
     cs = _cos(res["bf16"][1], res["fp32"][1])
     print(f"   ResNet-101 256x256 B=4: bf16 vs fp32 kernels out err/scale {err:.3e} (scale {scale:.2f}), input-grad cos {cs:.5f}")
-    assert err <= 5e-2 and cs >= 0.95
+    assert err <= 5e-2 and cs >= 0.975
     est = res["bf16"][2]
     with torch.no_grad():
         a = est(x.to(DEV))
