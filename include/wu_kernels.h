@@ -262,6 +262,15 @@ int wu_adain_style_fwd(const float* y, const float* w, const float* b, float eps
 int wu_adain_style_bwd(const float* d_std, const float* d_mean, const float* y, const float* y4, const float* y_std,
                        const float* y_mean, float* dw, float* db, int N, int C, int nc, int accumulate, void* stream);
 
+/* The same two calls for up to 4 AdaIN layers that share the conditioning input y -- the three decoder levels of a U-Net pass (cunet.py:59,66,73) --
+ * in ONE launch each (round 4).  Host arrays of `levels` entries: w / b / y_std / y_mean / y4 / dw / db pointers (b[i], y4[i], db[i] may be NULL), eps, C.
+ * Per level the arithmetic is the single call's: results are bit-identical. */
+int wu_adain_style_fwd_multi(int levels, const float* y, const float* const* w, const float* const* b, const float* eps,
+                             float* const* y_std, float* const* y_mean, float* const* y4, int N, const int* C, int nc, void* stream);
+int wu_adain_style_bwd_multi(int levels, const float* const* d_std, const float* const* d_mean, const float* y, const float* const* y4,
+                             const float* const* y_std, const float* const* y_mean, float* const* dw, float* const* db,
+                             int N, const int* C, int nc, int accumulate, void* stream);
+
 /* AdaIN instance statistics (utils.py:34-39,47): per (n,c) over H*W: stats[n][c] = {mean, rstd}
  * with rstd = 1/sqrt(unbiased_var + eps).  `scratch` holds N*C*2*WU_MAX_SPLITS floats (per-split partial
  * sums, folded in fixed order: results are bitwise reproducible). */

@@ -669,3 +669,56 @@ def test_graphed_estimator_grad_pass_is_bitwise_the_eager_node():
     g(_rand((4, 3, 64, 96), 8).to(DEV).requires_grad_(True))
     with pytest.raises(RuntimeError, match="replayed again"):
         ya.sum().backward()
+
+
+@pytest.mark.parametrize("n,nc", [(32, 5), (3, 7), (9, 32)])
+def test_adain_style_multi_is_bitwise_the_per_layer_calls(n, nc):
+    """The three AdaIN style MLPs of a U-Net pass (utils.py:41-48 at cunet.py:59,66,73) in one launch per direction
+    (wu_adain_style_{fwd,bwd}_multi) against three single calls: (y_std, y_mean) and the gradients into l1.weight / l1.bias bit-equal,
+    channel counts that differ per level (the level's row range ends inside a wave), N not a multiple of the 8 sample lanes; then the
+    whole network's forward and all 36 gradients with the batched call on and off."""
+    from wu import functional as WF, unet_graph as UG
+    DEV = _dev()
+    chans = (512, 256, 100)
+    y = _rand((n, nc), 1).to(DEV)
+    layers, single = [], []
+    for i, c in enumerate(chans):
+        w = _rand((4 * c, nc), 10 + i).to(DEV).requires_grad_(True)
+        b = _rand((4 * c,), 20 + i).to(DEV).requires_grad_(True)
+        layers.append((w, b, 1e-5 * (i + 1)))
+        single.append((w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)))
+    outs = WF.adain_style_multi(y, layers)
+    loss = 0
+    for i, (sd, mn) in enumerate(outs):
+        loss = loss + (sd * _rand(sd.shape, 30 + i).to(DEV)).sum() + (mn * _rand(mn.shape, 40 + i).to(DEV)).sum()
+    loss.backward()
+    for i, ((w1, b1), (w, b, eps)) in enumerate(zip(single, layers)):
+        sd, mn = WF.adain_style(y, w1, b1, eps)
+        ((sd * _rand(sd.shape, 30 + i).to(DEV)).sum() + (mn * _rand(mn.shape, 40 + i).to(DEV)).sum()).backward()
+        assert torch.equal(sd, outs[i][0]) and torch.equal(mn, outs[i][1]), f"level {i}: forward"
+        assert torch.isfinite(w.grad).all() and w.grad.abs().max().item() > 0
+        assert torch.equal(w.grad, w1.grad) and torch.equal(b.grad, b1.grad), f"level {i}: gradients"
+    if (n, nc) != (32, 5):
+        return
+    import cunet
+    torch.manual_seed(0)
+    net = cunet.Conditional_UNet(5, precision="bf16").to(DEV).train()
+    net.dropout_seed = 3
+    x = _rand((2, 3, 64, 64), 5).to(DEV)
+    c = torch.eye(5, device=DEV)[[1, 3]]
+    res = []
+    saved = UG.STYLE_BATCHED
+    try:
+        for flag in (True, False):
+            UG.STYLE_BATCHED = flag
+            net.dropout_seed = 3
+            net.zero_grad(set_to_none=True)
+            out = net(x, c)
+            torch.mean(torch.abs(out - x)).backward()
+            res.append((out.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    finally:
+        UG.STYLE_BATCHED = saved
+    assert torch.equal(res[0][0], res[1][0])
+    assert len(res[0][1]) == 36 and set(res[0][1]) == set(res[1][1])      # the reference's 36 trained tensors (the unused embeddings get none)
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k

@@ -71,6 +71,8 @@ SIGNATURES = {
     "wu_maxpool2_bwd": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I, P]),
     "wu_adain_style_fwd": (I, [P, P, P, F, P, P, P, I, I, I, P]),
     "wu_adain_style_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "wu_adain_style_fwd_multi": (I, [I, P, P, P, P, P, P, P, I, P, I, P]),
+    "wu_adain_style_bwd_multi": (I, [I, P, P, P, P, P, P, P, P, I, P, I, I, P]),
     "wu_adain_stats": (I, [P, I, P, P, I, I, I, I, F, I, P]),
     "wu_adain_upcat_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, F, U64, P, P, I, I, P]),
     "wu_adain_upcat_bwd": (I, [P, I, P, I, P, P, P, I, P, P, P, P, I, I, I, I, F, U64, P, I, I, P]),

@@ -571,3 +571,65 @@ class AdaINStyleFn(Function):
 
 def adain_style(y, weight, bias, eps):
     return AdaINStyleFn.apply(y, weight, bias, eps)
+
+
+class AdaINStyleMultiFn(Function):
+    """AdaINStyleFn for several AdaIN layers that share the conditioning input -- the three decoder levels of a U-Net pass (cunet.py:59,66,73) --
+    in ONE launch per direction (wu_adain_style_{fwd,bwd}_multi; per level the single call's arithmetic, bit-identical).
+    apply(y, eps_tuple, w0, b0, w1, b1, ...) -> (std0, mean0, std1, mean1, ...)."""
+
+    @staticmethod
+    def forward(ctx, y, eps, *wb):
+        import ctypes
+        n, nc = y.shape
+        y = y.contiguous()
+        ws = [w.detach().contiguous() for w in wb[0::2]]
+        bs = list(wb[1::2])
+        L = len(ws)
+        cs = [w.shape[0] // 4 for w in ws]
+        f32 = dict(dtype=torch.float32, device=y.device)
+        stds = [torch.empty((n, c), **f32) for c in cs]
+        means = [torch.empty((n, c), **f32) for c in cs]
+        y4s = [torch.empty((n, c, 4), **f32) for c in cs]
+        P, FA, IA = ctypes.c_void_p * L, ctypes.c_float * L, ctypes.c_int * L
+        _lib.call("wu_adain_style_fwd_multi", L, y.data_ptr(), P(*[w.data_ptr() for w in ws]), P(*[b.data_ptr() if b is not None else None for b in bs]),
+                  FA(*[float(e) for e in eps]), P(*[t.data_ptr() for t in stds]), P(*[t.data_ptr() for t in means]), P(*[t.data_ptr() for t in y4s]),
+                  n, IA(*cs), nc, stream_ptr())
+        ctx.save_for_backward(y, *y4s, *stds, *means)
+        ctx.meta = ([tuple(w.shape) for w in wb[0::2]], [b is not None for b in bs])
+        out = []
+        for s_, m_ in zip(stds, means):
+            out.extend((s_, m_))
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        wshapes, has_bias = ctx.meta
+        L = len(wshapes)
+        saved = ctx.saved_tensors
+        y, y4s, stds, means = saved[0], saved[1:1 + L], saved[1 + L:1 + 2 * L], saved[1 + 2 * L:1 + 3 * L]
+        n, nc = y.shape
+        f32 = dict(dtype=torch.float32, device=y.device)
+        d_std = [(g if g is not None else torch.zeros_like(stds[i])).float().contiguous() for i, g in enumerate(grads[0::2])]
+        d_mean = [(g if g is not None else torch.zeros_like(means[i])).float().contiguous() for i, g in enumerate(grads[1::2])]
+        dws = [torch.empty(ws, **f32) for ws in wshapes]
+        dbs = [torch.empty((ws[0],), **f32) if hb else None for ws, hb in zip(wshapes, has_bias)]
+        P, IA = ctypes.c_void_p * L, ctypes.c_int * L
+        _lib.call("wu_adain_style_bwd_multi", L, P(*[t.data_ptr() for t in d_std]), P(*[t.data_ptr() for t in d_mean]), y.data_ptr(),
+                  P(*[t.data_ptr() for t in y4s]), P(*[t.data_ptr() for t in stds]), P(*[t.data_ptr() for t in means]),
+                  P(*[t.data_ptr() for t in dws]), P(*[t.data_ptr() if t is not None else None for t in dbs]),
+                  n, IA(*[ws[0] // 4 for ws in wshapes]), nc, 0, stream_ptr())
+        out = [None, None]
+        for dw, db in zip(dws, dbs):
+            out.extend((dw, db))
+        return tuple(out)
+
+
+def adain_style_multi(y, layers):
+    """layers: [(l1.weight, l1.bias, eps), ...] (<= 4) -> [(y_std, y_mean), ...] from one launch (and one in backward)."""
+    flat = []
+    for w, b, _ in layers:
+        flat.extend((w, b))
+    out = AdaINStyleMultiFn.apply(y, tuple(float(e) for _, _, e in layers), *flat)
+    return [(out[2 * i], out[2 * i + 1]) for i in range(len(layers))]

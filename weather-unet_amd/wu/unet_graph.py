@@ -37,6 +37,8 @@ C3_WGRAD_ON_SIDE = os.environ.get("WU_C3_WGRAD_SIDE", "0") == "1"
 # the 1x1 head + tanh computed in the epilogue of the last decoder conv (csrc/conv3x3_mfma_v2.hip, GATED = 5; cunet.py:78-82) instead of by a
 # kernel of its own that re-reads the 64-channel tensor; an undifferentiated forward then never writes that tensor (round 4; A/B switch)
 HEAD_FUSED = os.environ.get("WU_HEAD_FUSED", "1") == "1"
+# the three AdaIN style MLPs of a pass in one launch per direction (wu_adain_style_{fwd,bwd}_multi); 0: one launch per layer (bit-identical)
+STYLE_BATCHED = os.environ.get("WU_STYLE_BATCHED", "1") == "1"
 _SIDE = {}
 _ORDER_EVENTS = {}
 LIGHT_EVENTS = os.environ.get("WU_LIGHT_EVENTS", "1") == "1"
@@ -423,8 +425,16 @@ def unet_forward(net, x, c, encoder_cache=None):
     code = precision_code(net.precision)
     c = c.to(device=x.device, dtype=torch.float32)
     styles = []
-    for adain in (net.adain3, net.adain2, net.adain1):
-        styles.extend(adain.style(c))
+    ads = (net.adain3, net.adain2, net.adain1)
+    if STYLE_BATCHED and c.is_cuda and not c.requires_grad and all(a.num_classes <= 32 for a in ads):
+        # the three style MLPs (utils.py:41-48) in one launch per direction instead of three dependent launch-sized kernels at the top of
+        # forward and at the very end of backward (bit-identical to the per-layer calls)
+        from . import functional as WF
+        for pair in WF.adain_style_multi(c, [(a.l1.weight, a.l1.bias, a.eps) for a in ads]):
+            styles.extend(pair)
+    else:
+        for adain in ads:
+            styles.extend(adain.style(c))
     params, packed = [], []
     for name in BLOCKS:
         blk = getattr(net, name)
