@@ -273,6 +273,35 @@ template <int E> __device__ __forceinline__ void keep_bits(uint64_t seed, uint64
     }
 }
 
+// Round 4: the same eight keep decisions as LANE MASKS of the packed bf16 chunk (dword i = elements 2i, 2i + 1: 0xffff per kept half) and as the keep byte,
+// without materialising eight bools (the compiler turned those into ~50 cndmask / shift / or instructions per chunk, more than the two splitmix64 draws,
+// in a kernel that issues VALU instructions back to back).  field < thr (unsigned 16-bit) == (field ^ 0x8000) < (thr ^ 0x8000) signed; the saturating packed
+// subtract keeps the sign, the packed arithmetic shift spreads it: three packed-int16 instructions per two elements.  thr <= 0xffff here.
+typedef short wu_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t keep_mask2(uint32_t fields, uint32_t thr_biased2) {
+    const wu_s16x2 x = __builtin_bit_cast(wu_s16x2, fields ^ 0x80008000u);
+    const wu_s16x2 d = __builtin_elementwise_sub_sat(x, __builtin_bit_cast(wu_s16x2, thr_biased2));
+    return __builtin_bit_cast(uint32_t, d >> (wu_s16x2)15);
+}
+__device__ __forceinline__ void keep_masks8(uint64_t seed, uint64_t idx, uint32_t thr, uint32_t (&m)[4], uint32_t& bits) {
+    const uint32_t tb = (thr ^ 0x8000u) & 0xffffu, tb2 = tb | (tb << 16);
+    const uint64_t r0 = wu_rand4(seed, idx >> 2), r1 = wu_rand4(seed, (idx >> 2) + 1);
+    m[0] = keep_mask2((uint32_t)r0, tb2);
+    m[1] = keep_mask2((uint32_t)(r0 >> 32), tb2);
+    m[2] = keep_mask2((uint32_t)r1, tb2);
+    m[3] = keep_mask2((uint32_t)(r1 >> 32), tb2);
+    const uint32_t v = (m[0] & 0x00020001u) | (m[1] & 0x00080004u) | (m[2] & 0x00200010u) | (m[3] & 0x00800040u);
+    bits = (v | (v >> 16)) & 0xffu;
+}
+// keep byte -> the four lane masks (caller-supplied masks)
+__device__ __forceinline__ void keep_masks_from_bits(uint32_t bits, uint32_t (&m)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t lo = (uint32_t)(-(int)((bits >> (2 * i)) & 1u)), hi = (uint32_t)(-(int)((bits >> (2 * i + 1)) & 1u));
+        m[i] = (lo & 0x0000ffffu) | (hi & 0xffff0000u);
+    }
+}
+
 // load E consecutive floats (E = 4 or 8) with 16-B loads
 template <int E> __device__ __forceinline__ void ldf(const float* __restrict__ p, float* o) {
 #pragma unroll
@@ -373,7 +402,7 @@ __global__ __launch_bounds__(256) void adain_upcat_fwd_kernel(const T* __restric
 // chunk: 0.75 loads instead of 4, one unpack per source value instead of one per tap.  Same values as adain_upcat_fwd_kernel up to
 // fp32 rounding order (the affine is applied before instead of after the interpolation).
 template <typename T>
-__global__ __launch_bounds__(256) void adain_upcat_fwd_march_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void adain_upcat_fwd_march_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ stats,
                                        const float* __restrict__ y_std, const float* __restrict__ y_mean,
                                        T* __restrict__ y, int ldy, int N, int H, int W, int C, int rows_per_strip, int col_tiles,
                                        float sy, float sx, uint32_t thr, float keep_scale, uint64_t seed,
@@ -381,13 +410,22 @@ __global__ __launch_bounds__(256) void adain_upcat_fwd_march_kernel(const T* __r
     constexpr int E = ElemTraits<T>::kPer16B;
     constexpr int LP = 64 / E, PP = 256 / LP;
     const int tid = threadIdx.x;
-    const int cg = blockIdx.x, n = blockIdx.z;
-    const int ctile = blockIdx.y % col_tiles, strip = blockIdx.y / col_tiles;
+    // XCD-aware decode (round 4): workgroups are dealt round-robin over the eight XCDs by their linear id; logical ids are remapped so that an XCD owns a
+    // contiguous range -- the channel groups of one pixel tile (they write interleaved 8-byte pieces of the same keep-byte lines: on two XCDs every
+    // such line left two L2s as two partial-line writes) and neighbouring tiles (shared source rows / columns) meet in one L2, dispatched together
+    // Measured (same box, profiles/r04_upcat_fwd.txt): 45 -> 38.6 us at C = 512 (eight groups per keep-byte line), no change at C = 256, 184 -> 193 us at C = 128
+    // (the data stream itself gets slower when an XCD's tiles are neighbours): remapped from eight channel groups up.
+    int bid = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    if (gridDim.x >= 8) bid = xcd_remap(bid, (int)(gridDim.x * gridDim.y * gridDim.z));
+    const int cg = bid % (int)gridDim.x; bid /= (int)gridDim.x;
+    const int by = bid % (int)gridDim.y, n = bid / (int)gridDim.y;
+    const int ctile = by % col_tiles, strip = by / col_tiles;
     const int cl = tid % LP, pl = tid / LP;
     const int c0 = cg * 64 + cl * E;
     const int cpp = C / E, chunk = c0 / E;
     const int H2 = 2 * H, W2 = 2 * W;
     const int j0 = 2 * (ctile * PP + pl), j1 = j0 + 1;                 // this thread's two output columns
+    const bool mask_store8 = E == 8 && ((uintptr_t)mbits & 7) == 0;    // (uniform) keep bytes leave as 8-byte words (cpp % 8 == 0: C % 64 == 0 here)
     if (j0 >= W2) return;
     const bool v1 = j1 < W2;
     if (seed_dev) seed += *seed_dev;
@@ -470,25 +508,54 @@ __global__ __launch_bounds__(256) void adain_upcat_fwd_march_kernel(const T* __r
             float o[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) o[e] = fmaf(l1w, b_[e], l0w * a_[e]);
-            if (thr < 0x10000u) {
-                bool keep[E];
-                if (mask_in) {
-                    const uint32_t bits = mbits[opix * cpp + chunk];
-#pragma unroll
-                    for (int e = 0; e < E; ++e) keep[e] = (bits >> e) & 1u;
-                } else {
-                    keep_bits<E>(seed, (uint64_t)opix * C + c0, thr, keep);
-                    if (mbits) {
-                        uint32_t bits = 0;
-#pragma unroll
-                        for (int e = 0; e < E; ++e) bits |= (keep[e] ? 1u : 0u) << e;
-                        mbits[opix * cpp + chunk] = (uint8_t)bits;
+            if constexpr (E == 8) {
+                // bf16: the keep decisions as lane masks ANDed onto the PACKED chunk (a dropped element is +0, as `keep ? o : 0.f` packs it)
+                uint4 pk = pack16<T>(o);
+                if (thr < 0x10000u) {
+                    uint32_t m[4], bits;
+                    if (mask_in) {
+                        bits = mbits[opix * cpp + chunk];
+                        keep_masks_from_bits(bits, m);
+                    } else {
+                        keep_masks8(seed, (uint64_t)opix * C + c0, thr, m, bits);
+                        if (mbits) {
+                            if (mask_store8) {
+                                // the eight chunk lanes of a pixel hold eight consecutive keep bytes: gathered into lane 0 of the group (two quad
+                                // DPP ORs + one row shift) and stored as ONE 8-byte word per pixel and 64-channel group instead of 64 byte stores per wave
+                                uint32_t v = bits << (8 * (cl & 3));
+                                v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+                                v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+                                const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0xf, true);   // row_shl:4 -> lane l reads lane l + 4
+                                if (cl == 0) *(uint2*)(mbits + opix * cpp + chunk) = make_uint2(v, hi);
+                            } else {
+                                mbits[opix * cpp + chunk] = (uint8_t)bits;
+                            }
+                        }
                     }
+                    pk.x &= m[0]; pk.y &= m[1]; pk.z &= m[2]; pk.w &= m[3];
                 }
+                *(uint4*)(y + opix * ldy + c0) = pk;
+            } else {
+                if (thr < 0x10000u) {
+                    bool keep[E];
+                    if (mask_in) {
+                        const uint32_t bits = mbits[opix * cpp + chunk];
 #pragma unroll
-                for (int e = 0; e < E; ++e) o[e] = keep[e] ? o[e] : 0.f;
+                        for (int e = 0; e < E; ++e) keep[e] = (bits >> e) & 1u;
+                    } else {
+                        keep_bits<E>(seed, (uint64_t)opix * C + c0, thr, keep);
+                        if (mbits) {
+                            uint32_t bits = 0;
+#pragma unroll
+                            for (int e = 0; e < E; ++e) bits |= (keep[e] ? 1u : 0u) << e;
+                            mbits[opix * cpp + chunk] = (uint8_t)bits;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < E; ++e) o[e] = keep[e] ? o[e] : 0.f;
+                }
+                *(uint4*)(y + opix * ldy + c0) = pack16<T>(o);
             }
-            *(uint4*)(y + opix * ldy + c0) = pack16<T>(o);
         }
     }
 }
