@@ -14,10 +14,19 @@
 // rows of a transposed read fall in four disjoint bank ranges.
 // Partial blocks go to per-split slabs; a second kernel sums the slabs in fixed order (deterministic),
 // transposes to OIHW and optionally accumulates into .grad.  dbias rides along (ci-block 0 only).
+#include <type_traits>
+#include <utility>
+
 #include "wu_common.h"
 #include "wgrad_internal.h"
 
 namespace {
+
+// compile-time loop f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) (as in conv3x3_wgrad_v2.hip: a 72-step `#pragma unroll` body stays rolled)
+template <typename F, int... I> __device__ __forceinline__ void wgrad_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void wgrad_static_for(F&& f) { wgrad_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct WgradArgs {
     const void* x; const void* dy; const void* y;
@@ -71,20 +80,30 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv3x3_wgrad_kernel
     // X item k of this thread = halo pixel (hy, hx), 16-byte slot sx; dY item k = tile pixel (ry, rx), slot sd.
     // staging items per thread: halo pixels x slots / 256 -- at most 585 x 8 (bf16, P = 128) / 325 x 16 (fp32, P = 64); the host checks
     constexpr int NX = STRIDE == 2 ? (sizeof(T) == 2 ? 19 : 21) : 1, ND = STRIDE == 2 ? (P * SLOTS + 255) / 256 : 1;
-    int xd[NX], dd[ND];                      // packed (hy << 20 | hx << 8 | slot), -1: no such item
+    // Round 4, second pass: every per-item quantity that does not depend on the tile is computed ONCE -- the byte offset of the item from the tile's origin
+    // (through a per-image buffer descriptor: rows below the image fall off its end and load zeros), its LDS address, its halo column and border flags.  A tile then
+    // costs three VALU instructions + one buffer load per item and one LDS write, no masks: the first version decoded, clamped and 64-bit-addressed every item of
+    // every tile (~3 000 instructions per tile on the ONE wave a SIMD holds: the kernel was issue-bound, SQ active 54 %, profiles/r04_s2_wgrad.txt).
+    unsigned x_voff[NX], x_meta[NX], d_voff[ND], y_voff[ND], d_meta[ND];       // meta = LDS byte offset | column << 17 | flags << 27 (1 top row, 2 left column, 4 valid)
     uint4 xr[NX], dr[ND], yr[ND];
-    unsigned xok = 0, dok = 0;
+    constexpr unsigned kOOB = 0x80000000u;
     if constexpr (STRIDE == 2) {
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
             const int item = tid + 256 * k, p_ = item / SLOTS, s_ = item % SLOTS;
             const int hy = p_ / a.halo_w, hx = p_ - hy * a.halo_w;
-            xd[k] = p_ < a.halo_pix ? (hy << 20 | hx << 8 | s_) : -1;
+            const bool ok = p_ < a.halo_pix;
+            x_voff[k] = ok ? (unsigned)(((hy * a.W + hx) * a.ldx + s_ * E) * (int)sizeof(T)) : kOOB;
+            x_meta[k] = (unsigned)(ok ? lds_off<T>(p_, hx, s_ * 16) : 0) | (unsigned)hx << 17 | ((hy == 0 ? 1u : 0u) | (hx == 0 ? 2u : 0u) | (ok ? 4u : 0u)) << 27;
         }
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
             const int item = tid + 256 * k, r_ = item / SLOTS, s_ = item % SLOTS;
-            dd[k] = item < P * SLOTS ? ((r_ >> a.tw_log2) << 20 | (r_ & (TW - 1)) << 8 | s_) : -1;
+            const int ry = r_ >> a.tw_log2, rx = r_ & (TW - 1);
+            const bool ok = item < P * SLOTS;
+            d_voff[k] = ok ? (unsigned)(((ry * a.Wo + rx) * a.lddy + s_ * E) * (int)sizeof(T)) : kOOB;
+            y_voff[k] = ok ? (unsigned)(((ry * a.Wo + rx) * a.ldy + s_ * E) * (int)sizeof(T)) : kOOB;
+            d_meta[k] = (unsigned)(ok ? lds_off<T>(r_, r_, s_ * 16) : 0) | (unsigned)rx << 17 | (ok ? 4u : 0u) << 27;
         }
     }
     auto tile_origin = [&](int tile, int& n, int& oh0, int& ow0) __attribute__((always_inline)) {
@@ -94,53 +113,78 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv3x3_wgrad_kernel
         n = tt / a.tiles_y;
         oh0 = ty * TH; ow0 = tx * TW;
     };
-    auto prefetch = [&](int tile) __attribute__((always_inline)) {       // STRIDE == 2: unconditional loads from clamped coordinates
+    auto u4 = [](auto v) __attribute__((always_inline)) { return __builtin_bit_cast(uint4, v); };
+    auto prefetch = [&](int tile) __attribute__((always_inline)) {       // STRIDE == 2: one buffer load per item; padding = out-of-range offsets (zeros)
         int n, oh0, ow0;
         tile_origin(tile, n, oh0, ow0);
-        const int ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
-        const T* xb = (const T*)a.x + (size_t)n * a.H * a.W * a.ldx + cib * 64;
-        const T* dyb = (const T*)a.dy + (size_t)n * a.Ho * a.Wo * a.lddy + cob * 64;
-        const T* yb = a.y ? (const T*)a.y + (size_t)n * a.Ho * a.Wo * a.ldy + cob * 64 : nullptr;
-        xok = 0; dok = 0;
+        n = __builtin_amdgcn_readfirstlane(n); oh0 = __builtin_amdgcn_readfirstlane(oh0); ow0 = __builtin_amdgcn_readfirstlane(ow0);
+        // X: descriptor base one row + one pixel BEFORE the image so that halo offsets are non-negative (for n = 0 it points before the tensor: the lanes that
+        // would touch those bytes are the flagged top-row / left-column ones); a pixel of row H or below lies past num_records
+        const T* xb = (const T*)a.x + ((long long)n * a.H * a.W - (a.W + 1)) * a.ldx + cib * 64;
+        const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)(((size_t)a.H * a.W + a.W + 1) * a.ldx * sizeof(T)), 0x00020000);
+        const int sox = (oh0 * STRIDE * a.W + ow0 * STRIDE) * a.ldx * (int)sizeof(T);
+        const unsigned border = (oh0 == 0 ? 1u : 0u) | (ow0 == 0 ? 2u : 0u);
+        const unsigned limx = (unsigned)(a.W - (ow0 * STRIDE - 1));               // halo columns >= limx lie right of the image
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
-            const int hy = xd[k] >> 20, hx = (xd[k] >> 8) & 0xfff, s_ = xd[k] & 0xff;
-            const int ih = ih0 + hy, iw = iw0 + hx;
-            if (xd[k] >= 0 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) xok |= 1u << k;
-            xr[k] = *(const uint4*)(xb + (size_t)(min(max(ih, 0), a.H - 1) * a.W + min(max(iw, 0), a.W - 1)) * a.ldx + s_ * E);
+            const bool bad = ((x_meta[k] >> 27) & border) != 0 || ((x_meta[k] >> 17) & 0x3ffu) >= limx;
+            xr[k] = u4(__builtin_amdgcn_raw_buffer_load_b128(rx_, (int)(bad ? kOOB : x_voff[k]), sox, 0));
         }
+        const T* dyb = (const T*)a.dy + (size_t)n * a.Ho * a.Wo * a.lddy + cob * 64;
+        const __amdgpu_buffer_rsrc_t rd_ = __builtin_amdgcn_make_buffer_rsrc((void*)dyb, 0, (int)((size_t)a.Ho * a.Wo * a.lddy * sizeof(T)), 0x00020000);
+        const int sod = (oh0 * a.Wo + ow0) * a.lddy * (int)sizeof(T);
+        const unsigned limd = (unsigned)(a.Wo - ow0);
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-            const int ry = dd[k] >> 20, rx = (dd[k] >> 8) & 0xfff, s_ = dd[k] & 0xff;
-            const int oh = oh0 + ry, ow = ow0 + rx;
-            if (dd[k] >= 0 && oh < a.Ho && ow < a.Wo) dok |= 1u << k;
-            const size_t o = (size_t)(min(oh, a.Ho - 1) * a.Wo + min(ow, a.Wo - 1));
-            dr[k] = *(const uint4*)(dyb + o * a.lddy + s_ * E);
-            if (yb) yr[k] = *(const uint4*)(yb + o * a.ldy + s_ * E);
+            const bool bad = ((d_meta[k] >> 17) & 0x3ffu) >= limd;
+            dr[k] = u4(__builtin_amdgcn_raw_buffer_load_b128(rd_, (int)(bad ? kOOB : d_voff[k]), sod, 0));
+        }
+        if (a.y) {
+            const T* yb = (const T*)a.y + (size_t)n * a.Ho * a.Wo * a.ldy + cob * 64;
+            const __amdgpu_buffer_rsrc_t ry_ = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, (int)((size_t)a.Ho * a.Wo * a.ldy * sizeof(T)), 0x00020000);
+            const int soy = (oh0 * a.Wo + ow0) * a.ldy * (int)sizeof(T);
+#pragma unroll
+            for (int k = 0; k < ND; ++k) {
+                const bool bad = ((d_meta[k] >> 17) & 0x3ffu) >= limd;
+                yr[k] = u4(__builtin_amdgcn_raw_buffer_load_b128(ry_, (int)(bad ? kOOB : y_voff[k]), soy, 0));
+            }
         }
     };
-    auto commit = [&]() __attribute__((always_inline)) {                // registers -> LDS (zero padding as lane masks)
+    auto commit = [&]() __attribute__((always_inline)) {                // registers -> LDS (padding arrived as zeros)
 #pragma unroll
-        for (int k = 0; k < NX; ++k) {
-            if (xd[k] >= 0) {
-                const int item = tid + 256 * k, p_ = item / SLOTS, hx = (xd[k] >> 8) & 0xfff, s_ = xd[k] & 0xff;
-                const uint32_t m = (xok >> k) & 1u ? 0xffffffffu : 0u;
-                *(uint4*)(x_lds + lds_off<T>(p_, hx, s_ * 16)) = make_uint4(xr[k].x & m, xr[k].y & m, xr[k].z & m, xr[k].w & m);
-            }
-        }
+        for (int k = 0; k < NX; ++k)
+            if ((x_meta[k] >> 29) & 1u) *(uint4*)(x_lds + (x_meta[k] & 0x1ffffu)) = xr[k];
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-            if (dd[k] >= 0) {
-                const int item = tid + 256 * k, r_ = item / SLOTS, s_ = dd[k] & 0xff;
-                uint4 w_ = dr[k];
-                if (a.y) w_ = gate16<T>(w_, yr[k], a.act);
-                const uint32_t m = (dok >> k) & 1u ? 0xffffffffu : 0u;
-                *(uint4*)(dy_lds + lds_off<T>(r_, r_, s_ * 16)) = make_uint4(w_.x & m, w_.y & m, w_.z & m, w_.w & m);
-            }
+            uint4 w_ = dr[k];
+            if (a.y) w_ = gate16<T>(w_, yr[k], a.act);
+            if ((d_meta[k] >> 29) & 1u) *(uint4*)(dy_lds + (d_meta[k] & 0x1ffffu)) = w_;
         }
     };
     if constexpr (STRIDE == 2) {
         if (split < a.ntiles) prefetch(split);
+    }
+    // Stride 2, bf16 (round 4): the fragment addresses of a K-step depend on the lane and the tile SHAPE only -- tile pixel r = 16 ks + 8 h + q (+ 4) sits at halo pixel
+    // (2 ry, 2 rx), and a tap adds (kh halo_w + kw) rows; the 64-byte swizzle bit of halo column 2 rx + kw is rx & 1 for kw = 0, 1 and its complement for kw = 2.  The
+    // runtime tile shape made the compiler recompute all of it per K-step and tap (~180 VALU instructions beside 9 MFMAs on the one wave of a SIMD).
+    constexpr int KSN = (sizeof(T) == 2 && STRIDE == 2) ? P / 16 : 1;
+    int fa_off[KSN][2], fb_off[KSN][2][2], tap_off[9];
+    if constexpr (sizeof(T) == 2 && STRIDE == 2) {
+        const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, h = g >> 1;
+        const int acb = (32 * wm + 16 * (g & 1) + 4 * pp) * 2, bcb = (32 * wn + 16 * (g & 1) + 4 * pp) * 2;
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = 16 * ks + 8 * h + q + 4 * u;
+                const int ry = r >> a.tw_log2, rx = r & (TW - 1);
+                const int hp = ry * STRIDE * a.halo_w + rx * STRIDE;
+                fa_off[ks][u] = lds_off<T>(r, r, acb);
+                fb_off[ks][u][0] = lds_off<T>(hp, rx * STRIDE, bcb);
+                fb_off[ks][u][1] = lds_off<T>(hp, rx * STRIDE + 2, bcb);
+            }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) tap_off[tap] = __builtin_amdgcn_readfirstlane(((tap / 3) * a.halo_w + tap % 3) * 128);
     }
 
     for (int tile = split; tile < a.ntiles; tile += a.splits) {
@@ -226,7 +270,35 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void conv3x3_wgrad_kernel
         }
 
         // ---- MFMA over the tile's pixels ----
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (sizeof(T) == 2 && STRIDE == 2) {
+            // tile-invariant fragment addresses (tables built once per workgroup); the 72 (K-step, tap) MFMAs of a tile software-pipelined by hand: the X fragment of
+            // step s + LA and the dY fragment of the next K-step are requested ahead of the MFMA of step s (one wave per SIMD: nothing else covers an LDS round trip --
+            // the compiler's own order was two reads / wait / MFMA, 54 exposed waits per tile); sched_barrier pins the order, the compiler counts the lgkmcnt waits
+            constexpr int KS = P / 16, NS = KS * 9, LA = 5;
+            auto load_a = [&](int ks) __attribute__((always_inline)) {
+                const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(dy_lds + fa_off[ks][0]));
+                const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(dy_lds + fa_off[ks][1]));
+                return make_uint4(((const uint32_t*)&a0)[0], ((const uint32_t*)&a0)[1], ((const uint32_t*)&a1)[0], ((const uint32_t*)&a1)[1]);
+            };
+            auto load_b = [&](int st) __attribute__((always_inline)) {
+                const int ks = st / 9, tap = st % 9, v = tap % 3 == 2 ? 1 : 0;
+                const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(x_lds + fb_off[ks][0][v] + tap_off[tap]));
+                const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(x_lds + fb_off[ks][1][v] + tap_off[tap]));
+                return make_uint4(((const uint32_t*)&b0)[0], ((const uint32_t*)&b0)[1], ((const uint32_t*)&b1)[0], ((const uint32_t*)&b1)[1]);
+            };
+            uint4 afr[2], bfr[LA + 1];
+            afr[0] = load_a(0);
+#pragma unroll
+            for (int j = 0; j < LA; ++j) bfr[j] = load_b(j);
+            wgrad_static_for<NS>([&](auto st_tag) __attribute__((always_inline)) {
+                constexpr int st = decltype(st_tag)::value, ks = st / 9, tap = st % 9;
+                if constexpr (st + LA < NS) bfr[(st + LA) % (LA + 1)] = load_b(st + LA);
+                if constexpr (tap == 3 && ks + 1 < KS) afr[(ks + 1) & 1] = load_a(ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, afr[ks & 1]), __builtin_bit_cast(bf16x8_t, bfr[st % (LA + 1)]), acc[tap], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else if constexpr (sizeof(T) == 2) {
             const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
             const int h = g >> 1;
             const int acb = (32 * wm + 16 * (g & 1) + 4 * pp) * 2;   // channel byte of this lane's A address
