@@ -39,6 +39,10 @@ C3_WGRAD_ON_SIDE = os.environ.get("WU_C3_WGRAD_SIDE", "0") == "1"
 HEAD_FUSED = os.environ.get("WU_HEAD_FUSED", "1") == "1"
 # the three AdaIN style MLPs of a pass in one launch per direction (wu_adain_style_{fwd,bwd}_multi); 0: one launch per layer (bit-identical)
 STYLE_BATCHED = os.environ.get("WU_STYLE_BATCHED", "1") == "1"
+# the decoder's dropout keep decisions travel to the backward as stored keep BYTES (1: the forward writes one byte per 16-byte chunk, the
+# backward's LDS-ring kernel reads them) or are drawn AGAIN from the counter hash by the backward's marching kernel (0: nothing stored; same
+# masks, bit-identical gradients).  A/B switch; a device-side seed offset (graph replay) or caller-supplied masks always store / read bytes.
+KEEP_BITS_STORED = os.environ.get("WU_KEEP_BITS", "1") == "1"
 _SIDE = {}
 _ORDER_EVENTS = {}
 LIGHT_EVENTS = os.environ.get("WU_LIGHT_EVENTS", "1") == "1"
@@ -276,15 +280,16 @@ class UNetFn(Function):
         ys = [t.detach().float().contiguous() for t in (ys3, ys2, ys1)]
         ym = [t.detach().float().contiguous() for t in (ym3, ym2, ym1)]
         st3 = K.adain_stats(b4, eps)
-        mb3 = K.adain_upcat(b4, st3, ys[0], ym[0], cat3, p_drop, seeds[0], want_bits, seed_dev, inj[0])
+        keep_stored = want_bits and (KEEP_BITS_STORED or seed_dev is not None)
+        mb3 = K.adain_upcat(b4, st3, ys[0], ym[0], cat3, p_drop, seeds[0], keep_stored, seed_dev, inj[0])
         u3a = mid_conv("dconv_up3", cat3, _new(n, 256, h // 4, w // 4, dt, dev))
         u3b = K.conv3x3(u3a, pk["dconv_up3.2"][0], wb["dconv_up3"][3], _new(n, 256, h // 4, w // 4, dt, dev), 1, RELU)
         st2 = K.adain_stats(u3b, eps)
-        mb2 = K.adain_upcat(u3b, st2, ys[1], ym[1], cat2, p_drop, seeds[1], want_bits, seed_dev, inj[1])
+        mb2 = K.adain_upcat(u3b, st2, ys[1], ym[1], cat2, p_drop, seeds[1], keep_stored, seed_dev, inj[1])
         u2a = mid_conv("dconv_up2", cat2, _new(n, 128, h // 2, w // 2, dt, dev))
         u2b = K.conv3x3(u2a, pk["dconv_up2.2"][0], wb["dconv_up2"][3], _new(n, 128, h // 2, w // 2, dt, dev), 1, RELU)
         st1 = K.adain_stats(u2b, eps)
-        mb1 = K.adain_upcat(u2b, st1, ys[2], ym[2], cat1, p_drop, seeds[2], want_bits, seed_dev, inj[2])
+        mb1 = K.adain_upcat(u2b, st1, ys[2], ym[2], cat1, p_drop, seeds[2], keep_stored, seed_dev, inj[2])
         u1a = mid_conv("dconv_up1", cat1, _new(n, 64, h, w, dt, dev))
         # ---- last decoder conv + head (cunet.py:78-82) ----
         w3c = w_last.detach().reshape(3, 64).contiguous()
