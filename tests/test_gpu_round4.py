@@ -722,3 +722,38 @@ def test_adain_style_multi_is_bitwise_the_per_layer_calls(n, nc):
     assert len(res[0][1]) == 36 and set(res[0][1]) == set(res[1][1])      # the reference's 36 trained tensors (the unused embeddings get none)
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# Dropout keep decisions (cunet.py:61,68,75): stored keep bytes (default) against drawn again by the backward (wu.unet_graph.KEEP_BITS_STORED,
+# WU_KEEP_BITS=0; measured not faster: profiles/r04_keep_bits_ab.txt).  Same masks: the forward is bit-identical; the backward kernels (LDS ring
+# reading bytes / marching kernel re-hashing, themselves compared bit for bit in test_gpu_kernels.py::test_adain_upcat_bwd_mask_bits_vs_rehash)
+# partition the per-(n, c) sums differently, so the gradients agree to bf16 rounding.
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_dropout_keep_bytes_stored_vs_redrawn_by_the_backward():
+    import cunet
+    from wu import unet_graph as UG
+    DEV = _dev()
+    torch.manual_seed(0)
+    net = cunet.Conditional_UNet(5, precision="bf16").to(DEV).train()
+    x = _rand((4, 3, 64, 64), 5).to(DEV)
+    c = torch.eye(5, device=DEV)[[1, 3, 0, 4]]
+    res = []
+    saved = UG.KEEP_BITS_STORED
+    try:
+        for flag in (True, False):
+            UG.KEEP_BITS_STORED = flag
+            net.dropout_seed = 11
+            net.zero_grad(set_to_none=True)
+            out = net(x, c)
+            torch.mean(torch.abs(out - x)).backward()
+            res.append((out.detach().clone(), {k: p.grad.double().clone() for k, p in net.named_parameters() if p.grad is not None}))
+    finally:
+        UG.KEEP_BITS_STORED = saved
+    assert torch.equal(res[0][0], res[1][0])
+    assert len(res[0][1]) == 36 and set(res[0][1]) == set(res[1][1])
+    for k, a in res[0][1].items():
+        b = res[1][1][k]
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos >= 0.9999, (k, cos)          # measured at B=32 256x256: worst relative L2 difference 6.4e-3 (cos 0.99998)
