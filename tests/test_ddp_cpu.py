@@ -423,3 +423,93 @@ def test_broadcast_invalidates_packed_operands_world2():
         # the premise: if torch ever starts bumping _version on collectives this still passes; it documents why we bump
         assert version_unmoved in (True, False)
     assert np.array_equal(res[0][6], res[1][6]) and np.array_equal(res[0][7], res[1][7])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# tail_mb (round 4): the LAST bucket's collective is the one nothing overlaps (profiles/r04_fake_collective.txt), so the last-ready parameters
+# get a small bucket of their own.  Layout on the real generator / discriminator, and a world-2 gloo run that the split changes nothing but
+# the launch schedule.
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+def test_tail_bucket_layout_on_the_real_networks():
+    sys.path.insert(0, os.path.join(ROOT, "weather-unet_amd"))
+    import cunet
+    import disc
+    from wu.ddp import GradBucketReducer, ready_order
+    net = cunet.Conditional_UNet(5, precision="fp32")
+    order = ready_order(net)
+    plain = GradBucketReducer(order, bucket_mb=12.0, ready_order=True)
+    sizes_plain = [b["flat"].numel() * 4 for b in plain.buckets]
+    plain.remove_hooks()
+    red = GradBucketReducer(order, bucket_mb=12.0, ready_order=True, tail_mb=1.0)
+    sizes = [b["flat"].numel() * 4 for b in red.buckets]
+    assert len(sizes) == len(sizes_plain) + 1 and sizes[:-2] == sizes_plain[:-1] and sizes[-2] + sizes[-1] == sizes_plain[-1]
+    assert sizes[-1] <= (1 << 20) and sizes[-1] + red.buckets[-2]["params"][-1].numel() * 4 > (1 << 20)     # the LARGEST suffix that fits
+    # same parameters, same order, every .grad a view of its bucket
+    flat_order = [p for b in red.buckets for p in b["params"]]
+    assert len(flat_order) == len(order) and all(a is b for a, b in zip(flat_order, order))
+    for b in red.buckets:
+        for p in b["params"]:
+            assert p.grad.untyped_storage().data_ptr() == b["flat"].untyped_storage().data_ptr()
+    # the tail holds the first encoder block and everything autograd delivers after the fused node (AdaIN style layers)
+    tail = {id(p) for p in red.buckets[-1]["params"]}
+    assert all(id(p) in tail for p in net.dconv_down1.parameters()) and all(id(p) in tail for p in net.adain1.parameters())
+    assert not any(id(p) in tail for p in net.dconv_down4.parameters())
+    red.remove_hooks()
+    # discriminator (registration order reversed = readiness order): one 9.3-MB bucket becomes a big one + a tail of the large-image layers
+    d = disc.SNDisc(5, precision="fp32")
+    dr = GradBucketReducer(list(d.parameters()), bucket_mb=12.0, tail_mb=1.0)
+    ds = [b["flat"].numel() * 4 for b in dr.buckets]
+    assert len(ds) == 2 and ds[1] <= (1 << 20) < ds[0]
+    tail = {id(p) for p in dr.buckets[-1]["params"]}
+    assert all(id(p) in tail for p in d.conv1.parameters()) and not any(id(p) in tail for p in d.conv4.parameters())
+    dr.remove_hooks()
+    # one parameter per bucket already: nothing to split; a tail limit smaller than the last parameter: nothing split either
+    m = _toy(0)
+    assert len(GradBucketReducer(list(m.parameters()), bucket_mb=1e-6, tail_mb=1.0).buckets) == len(list(m.parameters()))
+    assert len(GradBucketReducer(list(m.parameters()), bucket_mb=1.0, tail_mb=1e-9).buckets) == 1
+
+
+def _tail_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "weather-unet_amd"))
+    from wu.ddp import GradBucketReducer, shard_batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = []
+        for tail in (None, 200 * 4 / (1 << 20)):            # tail limit = 200 floats
+            m = _toy(seed=0)
+            red = GradBucketReducer(list(m.parameters()), bucket_mb=1.0, tail_mb=tail)       # one bucket without the split
+            torch.manual_seed(123)
+            x, y = torch.randn(8, 6), torch.randn(8, 1)
+            red.zero_grad()
+            torch.mean((m(shard_batch(x, rank, world)) - shard_batch(y, rank, world)) ** 2).backward()
+            inside = list(red.launch_log)
+            red.finalize()
+            out.append(([p.grad.detach().numpy().copy() for p in m.parameters()], inside, [len(b["params"]) for b in red.buckets]))
+            red.remove_hooks()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tail_bucket_world2_same_gradients_earlier_launch():
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_tail_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ((g_plain, in_plain, lay_plain), (g_tail, in_tail, lay_tail)) in res:
+        assert lay_plain == [7] and len(lay_tail) == 2 and sum(lay_tail) == 7, (lay_plain, lay_tail)
+        for a, b in zip(g_plain, g_tail):
+            assert np.array_equal(a, b)                   # an average of the same two numbers either way
+        # the single bucket holds the unused parameter: only finalize() launches it; with the split the first-ready part goes out during backward
+        assert in_plain == [] and in_tail == [0], (in_plain, in_tail)
+    for a, b in zip(res[0][1][1][0], res[1][1][1][0]):
+        assert np.array_equal(a, b)

@@ -31,6 +31,8 @@ class GradBucketReducer:
     ``params``     parameters in registration (forward) order; buckets are formed over the reversed list
                    (``ready_order=True``: the list already IS the order in which gradients become ready)
     ``bucket_mb``  target bucket size; the last-registered (first-ready) parameters fill bucket 0
+    ``tail_mb``    if given: the last-ready parameters (largest suffix of the last bucket within this size, at least one parameter stays)
+                   become a bucket of their own -- the one collective nothing can overlap is then a small one
 
     Gradients reach a bucket either through autograd (post-accumulate hooks) or, for the fused cUNet node whose
     gradients would otherwise all surface at once when the node returns, directly: ``attach(net)`` makes the node write
@@ -46,7 +48,7 @@ class GradBucketReducer:
     ``optimizer.zero_grad(set_to_none=True)``; use ``reducer.zero_grad()``).
     """
 
-    def __init__(self, params, bucket_mb=12.0, group=None, broadcast=True, ready_order=False):
+    def __init__(self, params, bucket_mb=12.0, group=None, broadcast=True, ready_order=False, tail_mb=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
@@ -57,15 +59,29 @@ class GradBucketReducer:
             raise ValueError("GradBucketReducer: parameters must be fp32 on one device")
         limit = int(bucket_mb * (1 << 20) / 4)
         self.buckets = []          # list of dict(flat, params, pending, work)
-        cur, cur_n = [], 0
+        groups, cur, cur_n = [], [], 0
         for p in (self.params if ready_order else reversed(self.params)):
             if cur and cur_n + p.numel() > limit:
-                self.buckets.append(self._make_bucket(cur, dev))
+                groups.append(cur)
                 cur, cur_n = [], 0
             cur.append(p)
             cur_n += p.numel()
         if cur:
-            self.buckets.append(self._make_bucket(cur, dev))
+            groups.append(cur)
+        # The LAST bucket completes with the last gradient of the backward pass: nothing is left to run beside its collective, its whole
+        # duration is added to the step (measured with a stand-in collective kernel: profiles/r04_fake_collective.txt).  ``tail_mb`` splits
+        # the last-ready parameters (the largest suffix that fits) into a bucket of their own, so that the exposed collective is a
+        # latency-sized one and the bytes before it travel beside the remaining kernels.
+        if tail_mb is not None and len(groups[-1]) > 1:
+            tail_limit = int(tail_mb * (1 << 20) / 4)
+            last, k, n = groups[-1], len(groups[-1]), 0
+            while k > 1 and n + last[k - 1].numel() <= tail_limit:
+                k -= 1
+                n += last[k].numel()
+            if k < len(last):
+                groups[-1:] = [last[:k], last[k:]]
+        for grp in groups:
+            self.buckets.append(self._make_bucket(grp, dev))
         self._bucket_of = {}
         self._hooks = []
         for bi, b in enumerate(self.buckets):
