@@ -171,9 +171,10 @@ def main():
     else:
         net.train()                            # Dropout(0.3) active, as in training (cunet.py:28)
         params = list(net.parameters())
-        # buckets in gradient-ready order, filled from inside the fused backward: all but the last bucket's all-reduce runs beside the
-        # remaining conv kernels, and the last one is cut to <= 1 MiB (tail_mb: its collective is the only one nothing overlaps)
-        reducer = GradBucketReducer(ready_order(net), bucket_mb=12.0, ready_order=True, tail_mb=1.0).attach(net) if use_ddp else None
+        # buckets in gradient-ready order, filled from inside the fused backward.  Layout from the stand-in measurements (profiles/r04_fake_collective.txt): ONE
+        # big bucket (29.4 MB, complete after down3.0's weight gradient, 1.2 ms before the end of the backward) + a tail of the last-ready 1.1 MB, whose collective is
+        # the only exposed one -- every overlapped collective costs about a third of its duration, so fewer is better as long as the last big one still fits
+        reducer = GradBucketReducer(ready_order(net), bucket_mb=32.0, ready_order=True, tail_mb=2.0).attach(net) if use_ddp else None
         opt = torch.optim.Adam(params, lr=1e-4, betas=(0.0, 0.999), weight_decay=1e-4 / 20, fused=True)   # t_cls_train.py:184
 
     def step():

@@ -44,7 +44,7 @@ def fake_all_reduce(t, op=None, group=None, async_op=False):
     with torch.cuda.stream(comm):
         if CFG["grid"] > 0:
             # usec < 0: duration from the message size -- 25 us + bytes / 70 GB/s (an 8-rank ring all-reduce over xGMI is per-link bound; assumption, see header)
-            usec = CFG["usec"] if CFG["usec"] >= 0 else int(25 + t.numel() * 4 / 70e3)
+            usec = CFG["usec"] if CFG["usec"] >= 0 else int(25 + t.numel() * 4 / (CFG.get("gbs", 70.0) * 1e3))
             rc = FC.fake_coll_launch(CFG["grid"], CFG["lds"], usec, ctypes.c_void_p(comm.cuda_stream))
             assert rc == 0, rc
         ev = torch.cuda.Event()
@@ -61,11 +61,11 @@ c = torch.eye(5)[torch.arange(32) % 5].to(dev)
 reducer = None
 
 
-def build(tail_mb):
+def build(tail_mb, bucket_mb=12.0):
     global reducer
     if reducer is not None:
         reducer.remove_hooks()
-    reducer = GradBucketReducer(ready_order(net), bucket_mb=12.0, ready_order=True, tail_mb=tail_mb).attach(net)
+    reducer = GradBucketReducer(ready_order(net), bucket_mb=bucket_mb, ready_order=True, tail_mb=tail_mb).attach(net)
     reducer.world = 2                  # take the collective path
     reducer._avg_op = True             # as on RCCL (native AVG: no division pass)
 
@@ -110,9 +110,19 @@ VARIANTS = [
     ("32 WG x (25 us + bytes / 70 GB/s), tail bucket 1 MiB", dict(grid=32, usec=-1), 0, 1.0),
     ("no collective kernel, tail bucket 1 MiB", dict(grid=0, usec=0), 0, 1.0),
 ]
+if len(sys.argv) > 1 and sys.argv[1] == "buckets":       # bucket-size sweep under the duration model, tail bucket on
+    VARIANTS = [("no collective kernel (events only)", dict(grid=0, usec=0), 0, (1.0, 12.0))]
+    for bmb in (4.0, 8.0, 12.0, 16.0, 32.0):
+        for tail in (0.25, 1.0, 4.0):
+            VARIANTS.append((f"model, bucket_mb {bmb:g}, tail_mb {tail:g}", dict(grid=32, usec=-1), 0, (tail, bmb)))
+if len(sys.argv) > 1 and sys.argv[1] == "sensitivity":   # the two layouts under a slower / faster collective than the 70 GB/s of the model
+    VARIANTS = [("no collective kernel (events only)", dict(grid=0, usec=0), 0, (1.0, 12.0))]
+    for gbs in (35.0, 70.0, 140.0):
+        for bmb, tail in ((12.0, 1.0), (32.0, 1.0), (32.0, 2.0), (32.0, 4.0)):
+            VARIANTS.append((f"25 us + bytes / {gbs:g} GB/s, bucket_mb {bmb:g}, tail_mb {tail:g}", dict(grid=32, usec=-1, gbs=gbs), 0, (tail, bmb)))
 for rnd in range(2):
     for name, cfg, cus, tail in VARIANTS:
-        build(tail)
+        build(*tail) if isinstance(tail, tuple) else build(tail)
         CFG.update(cfg)
         _lib.call("wu_set_option", 10, cus)
         LOG.clear()

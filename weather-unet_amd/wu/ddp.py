@@ -9,8 +9,11 @@ per-rank gradients equals the global-batch gradient.
 
 Design for xGMI (point-to-point links, ring collectives are per-link bound): the payload is small
 (31.2 MB fp32 for G, 9.3 MB for D) next to a multi-TFLOP step, so the goal is overlap and few launches,
-not bandwidth: 2-4 buckets, filled in REVERSE parameter order (decoder gradients are ready first), each
+not bandwidth: a few buckets, filled in REVERSE parameter order (decoder gradients are ready first), each
 bucket one flat fp32 buffer that the parameters' ``.grad`` tensors are views of (no gather/scatter copies).
+Round 4 (stand-in collective kernel beside the persistent conv kernels, profiles/r04_fake_collective.txt): the LAST
+bucket's collective is exposed whole and every overlapped one costs about a third of its duration, so the shipped
+layout is one big bucket that completes well before the end of the backward plus a small tail (``tail_mb``).
 """
 import torch
 import torch.distributed as dist

@@ -107,8 +107,8 @@ class WeatherTransferStep:
         self.ddp = is_distributed() if ddp is None else ddp
         self.g_red = self.d_red = None
         if self.ddp:
-            self.g_red = GradBucketReducer(ready_order(self.inference), bucket_mb=12.0, ready_order=True, tail_mb=1.0).attach(self.inference)
-            self.d_red = GradBucketReducer(list(self.discriminator.parameters()), bucket_mb=12.0, tail_mb=1.0)
+            self.g_red = GradBucketReducer(ready_order(self.inference), bucket_mb=32.0, ready_order=True, tail_mb=2.0).attach(self.inference)
+            self.d_red = GradBucketReducer(list(self.discriminator.parameters()), bucket_mb=32.0, tail_mb=2.0)
             broadcast_buffers(self.discriminator)      # SN weight_u / weight_v identical on every rank
 
     def _estimator_nograd(self, rand_images, images):
