@@ -23,7 +23,11 @@ from wu import unet_graph as UG
 
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
-FC = ctypes.CDLL(os.path.join(ROOT, "scratch", "micro", "fake_coll.so"))
+_SO = os.path.join(ROOT, "scratch", "micro", "fake_coll.so")
+if not os.path.exists(_SO):            # the .so is git-ignored: build it where the script runs (hipcc is on the GPU box too)
+    import subprocess
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", _SO[:-3] + ".hip", "-o", _SO])
+FC = ctypes.CDLL(_SO)
 FC.fake_coll_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 comm = torch.cuda.Stream(dev)
 CFG = {"grid": 0, "usec": 0, "lds": 16384}
